@@ -1,0 +1,297 @@
+"""Host-side owner of the device memory behind the training hot path.
+
+PyTorch is used here for plumbing only: HBM allocations, streams, (later) RCCL.
+All arithmetic of the train step runs in libanirec's HIP kernels.
+
+HBM layout (one rank):
+  W, M, V     [(n_user_rows + n_anime_rows), 128] fp32 each — embeddings and Adam moments,
+              users first then anime, so one dense Adam launch covers both tables
+  rowmap      [rows] int32 — per-step "row -> chunk list" map written by bwd, cleared by adam
+  state       anirec_state (136 B) — scalar head, BN moving stats, step cursors, metrics
+  epoch data  user_idx/anime_idx int32 + rating fp32 in shuffled epoch order (12 B/rating)
+  sched       anirec_step[n_steps] — start/count/alpha of every step of the epoch
+  workspace   per-step scratch + the prep arena (sorted batches + chunk tables)
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DIM
+
+
+def _dev_bytes(n, device):
+    return torch.zeros(int(n), dtype=torch.uint8, device=device)
+
+
+class TrainEngine:
+    def __init__(self, n_user_rows, n_anime_rows, max_batch, l2=1e-4, arena_steps=64,
+                 device="cuda:0", n_seg=1, my_seg=0, anime_dense=False):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.AnirecError("no GPU: the anime_recommendations_amd hot path needs an MI355X")
+        if not (1 <= max_batch <= _lib.MAX_BATCH):
+            raise ValueError("max_batch must be in 1..%d (got %d)" % (_lib.MAX_BATCH, max_batch))
+        self.device = torch.device(device)
+        self.n_user_rows, self.n_anime_rows = int(n_user_rows), int(n_anime_rows)
+        self.rows = self.n_user_rows + self.n_anime_rows
+        self.max_batch, self.arena_steps = int(max_batch), int(arena_steps)
+        self.l2 = float(l2)
+        self.n_seg, self.my_seg, self.anime_dense = int(n_seg), int(my_seg), bool(anime_dense)
+        dev = self.device
+        self.W = torch.zeros(self.rows, DIM, dtype=torch.float32, device=dev)
+        self.M = torch.zeros_like(self.W)
+        self.V = torch.zeros_like(self.W)
+        self.rowmap = torch.zeros(self.rows, dtype=torch.int32, device=dev)
+        self.state_buf = _dev_bytes(_lib.STATE_DTYPE.itemsize, dev)
+        self.packet_floats = int(self.lib.anirec_packet_floats(self.max_batch))
+        self.packets = torch.zeros(self.n_seg * self.packet_floats, dtype=torch.float32, device=dev)
+        ws = int(self.lib.anirec_train_workspace_bytes(self.max_batch, self.arena_steps))
+        if ws == 0:
+            raise _lib.AnirecError("anirec_train_workspace_bytes rejected the geometry")
+        self.workspace = _dev_bytes(ws, dev)
+        self.anime_grad = (torch.zeros(self.n_anime_rows * DIM + self.n_anime_rows,
+                                       dtype=torch.float32, device=dev)
+                           if self.anime_dense else None)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.user_idx = self.anime_idx = self.rating = self.sched = None
+        self.n_steps = 0
+        self._trainer = None
+        self._desc = None
+        self.set_head()
+
+    # ---- views ---------------------------------------------------------------------
+    @property
+    def U(self):
+        return self.W[: self.n_user_rows]
+
+    @property
+    def A(self):
+        return self.W[self.n_user_rows:]
+
+    # ---- state ---------------------------------------------------------------------
+    def read_state(self) -> np.ndarray:
+        self.stream.synchronize()
+        return np.frombuffer(self.state_buf.cpu().numpy().tobytes(), dtype=_lib.STATE_DTYPE)[0].copy()
+
+    def write_state(self, rec: np.ndarray) -> None:
+        self.stream.synchronize()
+        raw = np.frombuffer(np.asarray(rec, dtype=_lib.STATE_DTYPE).tobytes(), dtype=np.uint8).copy()
+        self.state_buf.copy_(torch.from_numpy(raw).to(self.device))
+        torch.cuda.synchronize(self.device)
+
+    def set_head(self, w=1.0, b=0.0, gamma=1.0, beta=0.0, mov_mean=0.0, mov_var=1.0,
+                 adam_m=None, adam_v=None):
+        rec = np.zeros((), dtype=_lib.STATE_DTYPE)
+        rec["w"], rec["b"], rec["gamma"], rec["beta"] = w, b, gamma, beta
+        rec["mov_mean"], rec["mov_var"] = mov_mean, mov_var
+        if adam_m is not None:
+            rec["adam_m"] = adam_m
+        if adam_v is not None:
+            rec["adam_v"] = adam_v
+        self.write_state(rec)
+
+    def set_weights(self, U, A):
+        """Load embedding tables (numpy or torch, fp32) and refresh the L2 partial sums."""
+        U = torch.as_tensor(U, dtype=torch.float32)
+        A = torch.as_tensor(A, dtype=torch.float32)
+        assert U.shape == (self.n_user_rows, DIM) and A.shape == (self.n_anime_rows, DIM)
+        self.stream.synchronize()
+        self.W[: self.n_user_rows].copy_(U)
+        self.W[self.n_user_rows:].copy_(A)
+        torch.cuda.synchronize(self.device)
+        self.init_reg()
+
+    def reset_optimizer(self):
+        self.stream.synchronize()
+        self.M.zero_()
+        self.V.zero_()
+        torch.cuda.synchronize(self.device)
+
+    # ---- descriptor ----------------------------------------------------------------
+    def _build_desc(self):
+        d = _lib.TrainDesc()
+        d.n_user_rows, d.n_anime_rows = self.n_user_rows, self.n_anime_rows
+        d.max_batch, d.arena_steps = self.max_batch, self.arena_steps
+        d.anime_dense, d.n_seg, d.my_seg = int(self.anime_dense), self.n_seg, self.my_seg
+        d.l2 = self.l2
+        d.W, d.M, d.V = _lib.ptr(self.W), _lib.ptr(self.M), _lib.ptr(self.V)
+        d.rowmap, d.state = _lib.ptr(self.rowmap), _lib.ptr(self.state_buf)
+        d.user_idx, d.anime_idx = _lib.ptr(self.user_idx), _lib.ptr(self.anime_idx)
+        d.rating, d.sched = _lib.ptr(self.rating), _lib.ptr(self.sched)
+        d.n_steps = self.n_steps
+        d.packets = _lib.ptr(self.packets)
+        d.anime_grad = _lib.ptr(self.anime_grad)
+        d.workspace, d.workspace_bytes = _lib.ptr(self.workspace), self.workspace.numel()
+        self._desc = d
+        if self._trainer is not None:
+            _lib.check(self.lib.anirec_trainer_destroy(self._trainer), "anirec_trainer_destroy")
+            self._trainer = None
+        return d
+
+    @property
+    def desc(self):
+        return self._desc if self._desc is not None else self._build_desc()
+
+    def _sp(self):
+        return C.c_void_p(self.stream.cuda_stream)
+
+    def init_reg(self):
+        _lib.check(self.lib.anirec_train_init_reg(C.byref(self.desc), self._sp()), "anirec_train_init_reg")
+
+    # ---- epoch data ----------------------------------------------------------------
+    def set_epoch(self, user_idx, anime_idx, rating, starts, counts, alphas, global_counts=None):
+        """Install one epoch: shuffled ratings (device int32/int32/fp32) + its step schedule."""
+        self.stream.synchronize()
+        dev = self.device
+        self.user_idx = torch.as_tensor(user_idx, device=dev).to(torch.int32).contiguous()
+        self.anime_idx = torch.as_tensor(anime_idx, device=dev).to(torch.int32).contiguous()
+        self.rating = torch.as_tensor(rating, device=dev).to(torch.float32).contiguous()
+        counts = np.asarray(counts, np.int32)
+        if counts.size and int(counts.max()) > self.max_batch:
+            raise ValueError("a step holds %d ratings > max_batch %d" % (counts.max(), self.max_batch))
+        sched = np.zeros(len(counts), dtype=_lib.STEP_DTYPE)
+        sched["start"], sched["count"], sched["alpha"] = starts, counts, alphas
+        sched["global_count"] = counts if global_counts is None else global_counts
+        raw = torch.from_numpy(np.frombuffer(sched.tobytes(), dtype=np.uint8).copy())
+        self.sched = raw.to(dev)
+        self.n_steps = len(counts)
+        rec = self.read_state()
+        rec["step_fwd"] = 0
+        rec["step_bwd"] = 0
+        self.write_state(rec)
+        self._build_desc()
+
+    def reset_metrics(self):
+        rec = self.read_state()
+        for k in ("loss_wsum", "se_sum", "n_seen", "val_bce_sum", "val_se_sum", "val_n"):
+            rec[k] = 0.0
+        self.write_state(rec)
+
+    # ---- stages (unit-testable) -----------------------------------------------------
+    def prep(self, first_step, n_steps):
+        _lib.check(self.lib.anirec_train_prep(C.byref(self.desc), first_step, n_steps, self._sp()),
+                   "anirec_train_prep")
+
+    def fwd(self):
+        _lib.check(self.lib.anirec_train_fwd(C.byref(self.desc), self._sp()), "anirec_train_fwd")
+
+    def head(self):
+        _lib.check(self.lib.anirec_train_head(C.byref(self.desc), self._sp()), "anirec_train_head")
+
+    def bwd(self):
+        _lib.check(self.lib.anirec_train_bwd(C.byref(self.desc), self._sp()), "anirec_train_bwd")
+
+    def adam(self):
+        _lib.check(self.lib.anirec_train_adam(C.byref(self.desc), self._sp()), "anirec_train_adam")
+
+    # ---- the hot loop ---------------------------------------------------------------
+    def run(self, n_steps=None, use_graph=True, first_step=None):
+        """Run n_steps optimiser steps from the current cursor (prep + fwd/head/bwd/adam)."""
+        if self.n_seg != 1 or self.anime_dense:
+            raise _lib.AnirecError("TrainEngine.run is the single-GPU loop; use DistTrainer")
+        if first_step is None:
+            first_step = int(self.read_state()["step_fwd"])
+        if n_steps is None:
+            n_steps = self.n_steps - first_step
+        if self._trainer is None:
+            h = C.c_void_p()
+            _lib.check(self.lib.anirec_trainer_create(C.byref(self.desc), C.byref(h)), "anirec_trainer_create")
+            self._trainer = h
+        done = 0
+        while done < n_steps:
+            blk = min(self.arena_steps, n_steps - done)
+            # keep (step % arena_steps) slots distinct inside one block
+            self.prep(first_step + done, blk)
+            _lib.check(self.lib.anirec_trainer_run(self._trainer, blk, int(use_graph), self._sp()),
+                       "anirec_trainer_run")
+            done += blk
+        return n_steps
+
+    def evaluate(self, user_idx, anime_idx, rating):
+        """Validation pass (BN inference). Returns (val_loss, val_mse) with Keras semantics."""
+        dev = self.device
+        u = torch.as_tensor(user_idx, device=dev).to(torch.int32).contiguous()
+        a = torch.as_tensor(anime_idx, device=dev).to(torch.int32).contiguous()
+        t = torch.as_tensor(rating, device=dev).to(torch.float32).contiguous()
+        rec = self.read_state()
+        rec["val_bce_sum"] = rec["val_se_sum"] = rec["val_n"] = 0.0
+        self.write_state(rec)
+        self.init_reg()  # reg_sumsq of the CURRENT weights
+        _lib.check(self.lib.anirec_eval(C.byref(self.desc), _lib.ptr(u), _lib.ptr(a), _lib.ptr(t),
+                                        int(u.numel()), self._sp()), "anirec_eval")
+        rec = self.read_state()
+        n = max(float(rec["val_n"]), 1.0)
+        val_loss = np.float32(rec["val_bce_sum"] / n) + np.float32(self.l2) * rec["reg_sumsq"]
+        return float(val_loss), float(rec["val_se_sum"] / n)
+
+    def epoch_metrics(self):
+        rec = self.read_state()
+        n = max(float(rec["n_seen"]), 1.0)
+        return float(rec["loss_wsum"] / n), float(rec["se_sum"] / n)
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    def close(self):
+        if self._trainer is not None:
+            self.stream.synchronize()
+            self.lib.anirec_trainer_destroy(self._trainer)
+            self._trainer = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- debug/test helper: python mirror of csrc/anirec_train.hip::carve() ----------------
+def _align(x, a=256):
+    return (x + a - 1) // a * a
+
+
+def workspace_layout(max_batch, arena_steps):
+    cap = max_batch
+    capC = (cap + cap // _lib.CHUNK + 2 + 3) & ~3
+    off = 0
+    lay = {"cap": cap, "capC": capC}
+    for name, nbytes in (("su", 4 * cap), ("sa", 4 * cap), ("coef", 4 * cap), ("selfu", 4 * cap),
+                         ("selfa", 4 * cap), ("regpart", 4 * _lib.ADAM_BLOCKS),
+                         ("P", 4 * 2 * capC * DIM), ("S", 4 * 2 * capC)):
+        lay[name] = (off, nbytes)
+        off += _align(nbytes)
+    a1 = _align(4 * 2 * cap)
+    lay["slot_bytes"] = _align(16) + 2 * a1 + _align(16 * 2 * capC)
+    lay["arena"] = off
+    lay["slot_sidx"] = 256
+    lay["slot_oth"] = 256 + a1
+    lay["slot_chunks"] = 256 + 2 * a1
+    lay["total"] = off + lay["slot_bytes"] * arena_steps
+    return lay
+
+
+def read_ws(engine, name, dtype=np.float32):
+    """Copy one named workspace array back to the host (tests only)."""
+    lay = workspace_layout(engine.max_batch, engine.arena_steps)
+    off, nbytes = lay[name]
+    engine.synchronize()
+    raw = engine.workspace[off:off + nbytes].cpu().numpy()
+    return np.frombuffer(raw.tobytes(), dtype=dtype)
+
+
+def read_slot(engine, step):
+    """Sorted-batch + chunk tables of one prepared step (tests only)."""
+    lay = workspace_layout(engine.max_batch, engine.arena_steps)
+    cap, capC = lay["cap"], lay["capC"]
+    base = lay["arena"] + lay["slot_bytes"] * (step % engine.arena_steps)
+    engine.synchronize()
+    raw = engine.workspace[base:base + lay["slot_bytes"]].cpu().numpy().tobytes()
+    nch = np.frombuffer(raw[:8], dtype=np.int32).copy()
+    sidx = np.frombuffer(raw[lay["slot_sidx"]:lay["slot_sidx"] + 8 * cap], dtype=np.int32).reshape(2, cap).copy()
+    oth = np.frombuffer(raw[lay["slot_oth"]:lay["slot_oth"] + 8 * cap], dtype=np.int32).reshape(2, cap).copy()
+    chunks = np.frombuffer(raw[lay["slot_chunks"]:lay["slot_chunks"] + 32 * capC], dtype=np.int32).reshape(2, capC, 4).copy()
+    return nch, sidx, oth, chunks

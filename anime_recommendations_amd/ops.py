@@ -1,0 +1,172 @@
+"""Thin torch-tensor wrappers over the inference / utility entry points of libanirec.
+
+Names follow the reference: ``get_weights`` row-normalisation (similar_anime.py:136-171),
+cosine neighbours (similar_users.py:290-296), ``model.predict`` (model_recs.py:394).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DIM, MAX_TOPK
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(x, device):
+    t = torch.as_tensor(x, device=device)
+    return t.to(torch.float32).contiguous()
+
+
+def _i32(x, device):
+    return torch.as_tensor(x, device=device).to(torch.int32).contiguous()
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.AnirecError("no GPU: the anime_recommendations_amd hot path needs an MI355X")
+
+
+def rownorm(W, device="cuda:0"):
+    """``W / np.linalg.norm(W, axis=1).reshape(-1, 1)`` on the GPU (fp32, no epsilon)."""
+    _need_gpu()
+    lib = _lib.load()
+    W = _f32(W, device)
+    assert W.dim() == 2 and W.shape[1] == DIM
+    out = torch.empty_like(W)
+    _lib.check(lib.anirec_rownorm(_lib.ptr(W), W.shape[0], _lib.ptr(out), _stream()), "anirec_rownorm")
+    return out
+
+
+def cosine_scores(What, q):
+    """``np.dot(What, What[q])`` with the library's fixed fp32 summation order."""
+    _need_gpu()
+    lib = _lib.load()
+    assert What.is_cuda and What.dtype == torch.float32 and What.shape[1] == DIM
+    out = torch.empty(What.shape[0], dtype=torch.float32, device=What.device)
+    _lib.check(lib.anirec_cosine_scores(_lib.ptr(What), What.shape[0], int(q), _lib.ptr(out), _stream()),
+               "anirec_cosine_scores")
+    return out
+
+
+def cosine_topk(What, queries, k, exclude_self=True, keep=None, workspace=None):
+    """Top-k rows by descending cosine for each query row index.
+
+    Returns (idx int32 [nq,k], score fp32 [nq,k]); padded with -1 / NaN.
+    Ties -> ascending row index; NaN scores rank last.
+    """
+    _need_gpu()
+    lib = _lib.load()
+    assert What.is_cuda and What.dtype == torch.float32 and What.shape[1] == DIM
+    if not (1 <= k <= MAX_TOPK):
+        raise ValueError("k must be in 1..%d" % MAX_TOPK)
+    dev = What.device
+    n = What.shape[0]
+    q = _i32(queries, dev)
+    nq = int(q.numel())
+    if nq and (int(q.min()) < 0 or int(q.max()) >= n):
+        raise ValueError("query row out of range")
+    out_i = torch.empty(nq, k, dtype=torch.int32, device=dev)
+    out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
+    if nq == 0:
+        return out_i, out_s
+    keep_t = None
+    if keep is not None:
+        keep_t = torch.as_tensor(keep, device=dev).to(torch.uint8).contiguous()
+        assert keep_t.numel() == n
+    if workspace is None:
+        workspace = torch.empty(int(lib.anirec_topk_workspace_bytes(n, nq)), dtype=torch.uint8, device=dev)
+    _lib.check(lib.anirec_cosine_topk(_lib.ptr(What), n, _lib.ptr(q), nq, _lib.ptr(keep_t),
+                                      int(bool(exclude_self)), int(k), _lib.ptr(out_i), _lib.ptr(out_s),
+                                      _lib.ptr(workspace), workspace.numel(), _stream()),
+               "anirec_cosine_topk")
+    return out_i, out_s
+
+
+def _head_struct(head):
+    return _lib.Head(float(head["w"]), float(head["b"]), float(head["gamma"]), float(head["beta"]),
+                     float(head["mov_mean"]), float(head["mov_var"]))
+
+
+def predict_pairs(U, A, head, user_idx, anime_idx):
+    """``model.predict([user_arr, anime_arr]).flatten()`` (BN inference mode)."""
+    _need_gpu()
+    lib = _lib.load()
+    dev = U.device
+    ui, ai = _i32(user_idx, dev), _i32(anime_idx, dev)
+    assert ui.numel() == ai.numel()
+    p = torch.empty(ui.numel(), dtype=torch.float32, device=dev)
+    h = _head_struct(head)
+    _lib.check(lib.anirec_predict_pairs(_lib.ptr(U), _lib.ptr(A), _lib.ptr(ui), _lib.ptr(ai),
+                                        int(ui.numel()), C.byref(h), _lib.ptr(p), _stream()),
+               "anirec_predict_pairs")
+    return p
+
+
+def predict_grid(U, A, head, users):
+    """Predicted rating of every anime for each listed user -> [len(users), n_anime] fp32."""
+    _need_gpu()
+    lib = _lib.load()
+    dev = U.device
+    us = _i32(users, dev)
+    n_a, n_q = A.shape[0], int(us.numel())
+    out = torch.empty(n_q, n_a, dtype=torch.float32, device=dev)
+    ws = torch.empty(int(lib.anirec_predict_workspace_bytes(n_a, max(n_q, 1), 0)), dtype=torch.uint8, device=dev)
+    h = _head_struct(head)
+    _lib.check(lib.anirec_predict_grid(_lib.ptr(U), _lib.ptr(A), n_a, _lib.ptr(us), n_q, C.byref(h),
+                                       _lib.ptr(out), _lib.ptr(ws), ws.numel(), _stream()),
+               "anirec_predict_grid")
+    return out
+
+
+def predict_topk(U, A, head, users, k, watched_bits=None):
+    """Top-k unwatched anime by predicted rating per user.  watched_bits: uint32/int32
+    [n_users, ceil(n_anime/32)] (bit set = watched) or None."""
+    _need_gpu()
+    lib = _lib.load()
+    dev = U.device
+    us = _i32(users, dev)
+    n_a, n_q = A.shape[0], int(us.numel())
+    out_i = torch.empty(n_q, k, dtype=torch.int32, device=dev)
+    out_p = torch.empty(n_q, k, dtype=torch.float32, device=dev)
+    if n_q == 0:
+        return out_i, out_p
+    wb = None
+    if watched_bits is not None:
+        wb = torch.as_tensor(watched_bits, device=dev).to(torch.int32).contiguous()
+        assert wb.shape == (n_q, (n_a + 31) // 32)
+    ws = torch.empty(int(lib.anirec_predict_workspace_bytes(n_a, n_q, 1)), dtype=torch.uint8, device=dev)
+    h = _head_struct(head)
+    _lib.check(lib.anirec_predict_topk(_lib.ptr(U), _lib.ptr(A), n_a, _lib.ptr(us), n_q, C.byref(h),
+                                       _lib.ptr(wb), int(k), _lib.ptr(out_i), _lib.ptr(out_p),
+                                       _lib.ptr(ws), ws.numel(), _stream()), "anirec_predict_topk")
+    return out_i, out_p
+
+
+def adam_flat(w, m, v, g, alpha):
+    """In-place Keras-2.12 Adam dense update of flat fp32 tensors (bit-exact vs the oracle)."""
+    _need_gpu()
+    lib = _lib.load()
+    _lib.check(lib.anirec_adam_flat(_lib.ptr(w), _lib.ptr(m), _lib.ptr(v), _lib.ptr(g), w.numel(),
+                                    float(np.float32(alpha)), _stream()), "anirec_adam_flat")
+
+
+def gather_ratings(user_idx, anime_idx, rating, perm):
+    """Epoch shuffle: returns the three rating columns permuted by ``perm`` (int64)."""
+    _need_gpu()
+    lib = _lib.load()
+    dev = user_idx.device
+    perm = torch.as_tensor(perm, device=dev).to(torch.int64).contiguous()
+    n = perm.numel()
+    uo = torch.empty(n, dtype=torch.int32, device=dev)
+    ao = torch.empty(n, dtype=torch.int32, device=dev)
+    to = torch.empty(n, dtype=torch.float32, device=dev)
+    _lib.check(lib.anirec_gather_ratings(_lib.ptr(user_idx), _lib.ptr(anime_idx), _lib.ptr(rating),
+                                         _lib.ptr(perm), n, _lib.ptr(uo), _lib.ptr(ao), _lib.ptr(to),
+                                         _stream()), "anirec_gather_ratings")
+    return uo, ao, to

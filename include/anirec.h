@@ -1,0 +1,229 @@
+/*
+ * anirec.h — C ABI of libanirec.so, the MI355X (gfx950) kernel library behind the
+ * anime_recommendations hot path.
+ *
+ * The reference (Dyrutter/anime_recommendations) is pure Python; its "plugin API" for
+ * this path is the MLflow component surface (neural_network, similar_anime,
+ * similar_users, model_recs) and the arithmetic lives in TensorFlow/Keras 2.12 and
+ * NumPy calls made from those components.  Every entry point below replaces one such
+ * call site (cited as reference file:line).  A maintainer of the reference would bind
+ * them with ctypes (INTEGRATION.md shows the stubs).
+ *
+ * Conventions
+ *  - extern "C", plain pointers + sizes, no C++/torch types.
+ *  - every pointer is a DEVICE pointer unless the name ends in _host.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *  - return value: 0 = ok, negative = ANIREC_E*, positive = hipError_t.
+ *  - the library never allocates device memory and never synchronises the stream
+ *    (exception: the *_create/_destroy calls, which touch no stream work);
+ *    all work is stream-ordered and graph-capturable.
+ *  - embedding rows are fp32, row-major, exactly ANIREC_DIM (=128) wide
+ *    (reference: config/config.yaml:63 embedding_size: 128).
+ */
+#ifndef ANIREC_H
+#define ANIREC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANIREC_ABI_VERSION 1
+#define ANIREC_DIM 128          /* embedding width (floats) */
+#define ANIREC_MAX_BATCH 16384  /* ratings per rank per step handled by one sort workgroup */
+#define ANIREC_CHUNK 32         /* max gradient contributions summed by one half-wave */
+#define ANIREC_ADAM_BLOCKS 2048 /* grid of the dense Adam kernel == length of reg partials */
+#define ANIREC_MAX_TOPK 128     /* k limit of the fused top-k kernels */
+
+enum {
+  ANIREC_OK = 0,
+  ANIREC_EINVAL = -1,     /* bad argument (null pointer, size out of range, dim != 128) */
+  ANIREC_ENODEVICE = -2,  /* no HIP device / wrong architecture */
+  ANIREC_EWORKSPACE = -3, /* workspace too small */
+  ANIREC_ECAPTURE = -4    /* graph capture / instantiate failed */
+};
+
+int anirec_abi_version(void);
+/* Human-readable text for a status code returned by this library. */
+const char *anirec_status_string(int status);
+/* Name of the device the library would run on; returns status. */
+int anirec_device_name(char *buf_host, size_t buf_len);
+
+/* ------------------------------------------------------------------------- *
+ *  TRAINING  — replaces model.fit's train step, neural_network/neural_network.py:210-217
+ *  (graph built at :66-106: Embedding x2 -> Dot(normalize) -> Dense(1) -> BatchNorm
+ *   -> sigmoid; binary_crossentropy + whole-table L2; Keras-2.12 Adam, dense update).
+ * ------------------------------------------------------------------------- */
+
+/* One optimiser step of the schedule.  `alpha` is the bias-corrected Adam step size
+ * lr*sqrt(1-b2^t)/(1-b1^t) for this step, computed on the host from lrfn(epoch)
+ * (neural_network.py:109-125) so host and oracle agree bit-for-bit. */
+typedef struct anirec_step {
+  int32_t start; /* first rating of this rank's part of the batch in the epoch arrays */
+  int32_t count; /* ratings of this rank in the batch (<= max_batch) */
+  float alpha;
+  int32_t global_count; /* ratings of the batch over all ranks (== count on one GPU) */
+} anirec_step;
+
+/* Device-resident scalar state; one instance per model.  Layout is ABI. */
+typedef struct anirec_state {
+  /* trainable scalars: Dense(1) kernel/bias (neural_network.py:97), BN gamma/beta (:99) */
+  float w, b, gamma, beta;
+  float adam_m[4], adam_v[4]; /* Adam slots of the four scalars, same order */
+  float mov_mean, mov_var;    /* BatchNormalization moving statistics */
+  float reg_sumsq;            /* sum(U^2)+sum(A^2) of the CURRENT tables (L2 term / lambda) */
+  float bn_mu, bn_var;        /* batch statistics of the last training step */
+  float last_loss, last_mse;  /* total loss (incl. L2) and mse of the last training step */
+  int32_t step_fwd;           /* schedule cursor of the next fwd+head */
+  int32_t step_bwd;           /* schedule cursor of the next bwd+adam */
+  int32_t pad0;
+  /* epoch accumulators (Keras History semantics: sample-weighted means) */
+  double loss_wsum;   /* sum over steps of count*total_loss */
+  double se_sum;      /* sum of squared errors (mse numerator) */
+  double n_seen;      /* ratings seen */
+  /* validation accumulators, BN inference mode (neural_network.py:216) */
+  double val_bce_sum; /* sum of per-row BCE */
+  double val_se_sum;
+  double val_n;
+} anirec_state;
+
+typedef struct anirec_train_desc {
+  int32_t n_user_rows;  /* user rows held by this rank */
+  int32_t n_anime_rows; /* anime rows (replicated) */
+  int32_t max_batch;    /* capacity of per-step buffers, 1..ANIREC_MAX_BATCH */
+  int32_t arena_steps;  /* number of steps the prep arena holds */
+  int32_t anime_dense;  /* 0: anime gradient stays chunked (1 GPU); 1: bwd writes the dense
+                           buffer `anime_grad`, the caller all-reduces it (RCCL), adam reads it */
+  int32_t n_seg;        /* head packets to read: 1 on one GPU, world size when all-gathered */
+  int32_t my_seg;       /* this rank's packet */
+  int32_t pad0;
+  float l2;             /* lambda of embeddings_regularizer L2 (neural_network.py:73) */
+  float pad1;
+  /* tables: rows [0,n_user_rows) users, then n_anime_rows anime; [rows][128] fp32.
+   * W = embeddings, M/V = Adam first/second moments. */
+  float *W, *M, *V;
+  int32_t *rowmap;      /* [n_user_rows+n_anime_rows]; zero before first use, left zero */
+  anirec_state *state;
+  /* this rank's ratings in epoch (shuffled) order; user_idx are LOCAL user rows */
+  const int32_t *user_idx;
+  const int32_t *anime_idx;
+  const float *rating;
+  const anirec_step *sched; /* [n_steps] */
+  int32_t n_steps;
+  int32_t pad2;
+  /* head packets: n_seg packets of anirec_packet_floats(max_batch) floats each; packet
+   * my_seg is written by the fwd kernel, the others by the caller's all-gather. */
+  float *packets;
+  float *anime_grad;    /* [n_anime_rows*128 + n_anime_rows] or NULL */
+  void *workspace;      /* >= anirec_train_workspace_bytes(max_batch, arena_steps) */
+  size_t workspace_bytes;
+} anirec_train_desc;
+
+/* floats in one head packet: c[max_batch], t[max_batch], 4 ints {count,0,0,0} */
+size_t anirec_packet_floats(int32_t max_batch);
+size_t anirec_train_workspace_bytes(int32_t max_batch, int32_t arena_steps);
+
+/* state.reg_sumsq <- sum(W^2) (both tables).  Call once after (re)loading weights. */
+int anirec_train_init_reg(const anirec_train_desc *d, void *stream);
+
+/* Sort each batch of steps [first_step, first_step+n_steps) by table row and cut the
+ * per-row runs into chunks (<= ANIREC_CHUNK ratings) for the backward pass.  Results
+ * land in arena slot (step % arena_steps).  Replaces TF's IndexedSlices ->
+ * unsorted_segment_sum densification inside model.fit. */
+int anirec_train_prep(const anirec_train_desc *d, int32_t first_step, int32_t n_steps, void *stream);
+
+/* The four stages of one step.  They read the step index from state->step_fwd /
+ * state->step_bwd so that a captured graph can be replayed for every step:
+ *   fwd  : gather U[ui], A[ai]; c = <l2n(u), l2n(a)>      -> packet, su, sa
+ *   head : Dense(1) + BatchNorm(batch stats) + sigmoid + BCE, closed-form backward to
+ *          d loss / d c, Adam on the 4 scalars, moving stats, epoch metrics; step_fwd++
+ *   bwd  : per-chunk weighted row sums of the OTHER table -> chunk partials (+rowmap)
+ *   adam : dense fused Adam over every row of both tables, g = sparse + 2*l2*W,
+ *          also emits sum(W_new^2) partials; step_bwd++                                  */
+int anirec_train_fwd(const anirec_train_desc *d, void *stream);
+int anirec_train_head(const anirec_train_desc *d, void *stream);
+int anirec_train_bwd(const anirec_train_desc *d, void *stream);
+int anirec_train_adam(const anirec_train_desc *d, void *stream);
+
+/* n_steps full steps (fwd, head, bwd, adam) starting at state->step_fwd.
+ * use_graph != 0 replays a captured hipGraph of `graph_steps` steps per launch. */
+typedef struct anirec_trainer anirec_trainer; /* host-side handle: descriptor copy + graph cache */
+int anirec_trainer_create(const anirec_train_desc *d, anirec_trainer **out_host);
+int anirec_trainer_destroy(anirec_trainer *t);
+int anirec_trainer_run(anirec_trainer *t, int32_t n_steps, int32_t use_graph, void *stream);
+
+/* Validation pass on n rows (BN inference, moving stats): accumulates
+ * state->val_* ; val_loss = val_bce_sum/val_n + l2*reg_sumsq  (neural_network.py:216). */
+int anirec_eval(const anirec_train_desc *d, const int32_t *user_idx, const int32_t *anime_idx,
+                const float *rating, int32_t n, void *stream);
+
+/* Standalone fused Adam on a flat fp32 array with an explicit dense gradient
+ * (Keras-2.12 Adam dense branch; bit-exact to the oracle given the same g). */
+int anirec_adam_flat(float *w, float *m, float *v, const float *g, size_t n, float alpha,
+                     void *stream);
+
+/* Epoch shuffle: out[i] = in[perm[i]] for the three rating columns (model.fit shuffle=True). */
+int anirec_gather_ratings(const int32_t *user_in, const int32_t *anime_in, const float *rating_in,
+                          const int64_t *perm, size_t n, int32_t *user_out, int32_t *anime_out,
+                          float *rating_out, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ *  SIMILARITY — replaces get_weights + np.dot + np.argsort,
+ *  similar_anime/similar_anime.py:136-171,404-408 ; similar_users/similar_users.py:75-101,293-296
+ * ------------------------------------------------------------------------- */
+
+/* What = W / ||W||_2 row-wise, no epsilon (zero row -> NaN like NumPy). */
+int anirec_rownorm(const float *W, int32_t n, float *What, void *stream);
+
+/* scores[j] = <What[j], What[q]> for every row j (k-ordered fp32 fma chain). */
+int anirec_cosine_scores(const float *What, int32_t n, int32_t q, float *scores, void *stream);
+
+/* Top-k rows by descending score for a batch of query rows of the same table.
+ *   queries[nq]   : query row indices
+ *   keep[n]       : optional byte mask (1 = candidate allowed), NULL = all
+ *   exclude_self  : drop the query row itself (similar_users.py:303, similar_anime.py:459)
+ *   out_idx[nq*k] : row indices (-1 padded), out_score[nq*k] : fp32 scores (NaN padded)
+ * Ties: ascending row index.  NaN scores rank last.  k <= ANIREC_MAX_TOPK.
+ * workspace: anirec_topk_workspace_bytes(n, nq) bytes. */
+size_t anirec_topk_workspace_bytes(int32_t n, int32_t nq);
+int anirec_cosine_topk(const float *What, int32_t n, const int32_t *queries, int32_t nq,
+                       const uint8_t *keep, int32_t exclude_self, int32_t k, int32_t *out_idx,
+                       float *out_score, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ *  PREDICTION — replaces model.predict([user_arr, anime_arr]), model_recs/model_recs.py:394
+ * ------------------------------------------------------------------------- */
+
+/* Inference head: sigmoid(gamma*(w*c+b-mov_mean)/sqrt(mov_var+1e-3)+beta). */
+typedef struct anirec_head {
+  float w, b, gamma, beta, mov_mean, mov_var;
+} anirec_head;
+
+/* p[i] = model(user_idx[i], anime_idx[i]) for n explicit pairs. */
+int anirec_predict_pairs(const float *U, const float *A, const int32_t *user_idx,
+                         const int32_t *anime_idx, int32_t n, const anirec_head *head_host,
+                         float *p, void *stream);
+
+/* Workspace of predict_grid / predict_topk: l2-normalised copies of A and of the query
+ * users (+ a batch of rating rows when topk != 0). */
+size_t anirec_predict_workspace_bytes(int32_t n_anime, int32_t n_users, int32_t topk);
+
+/* out[j*n_anime + a] = model(users[j], a) for every anime a (the full rating grid). */
+int anirec_predict_grid(const float *U, const float *A, int32_t n_anime, const int32_t *users,
+                        int32_t n_users, const anirec_head *head_host, float *out,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* Per query user: top-k anime by descending predicted rating among anime whose
+ * watched bit is clear.  watched: optional [n_users][ceil(n_anime/32)] bitmask words.
+ * (model_recs.py:144-155 candidate set, :396 ranking, :451-454 cut). */
+int anirec_predict_topk(const float *U, const float *A, int32_t n_anime, const int32_t *users,
+                        int32_t n_users, const anirec_head *head_host, const uint32_t *watched,
+                        int32_t k, int32_t *out_idx, float *out_p, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANIREC_H */
