@@ -67,12 +67,20 @@ __device__ __forceinline__ void block_sum(float (&v)[N], float *scratch) {
   }
 }
 
-// IEEE, never contracted into FMA: the fused Adam must be bit-identical to the
-// NumPy fp32 oracle given the same gradient.
+// IEEE, never contracted into FMA (HIP's __fmul_rn/__fadd_rn are plain operators and hipcc
+// defaults to -ffp-contract=fast, so contraction is switched off per block): the fused Adam
+// must be bit-identical to the NumPy fp32 oracle given the same gradient.
 __device__ __forceinline__ void adam_elem(float &w, float &m, float &v, float g, float alpha) {
-  m = __fadd_rn(m, __fmul_rn(__fsub_rn(g, m), kOneMinusB1));
-  v = __fadd_rn(v, __fmul_rn(__fsub_rn(__fmul_rn(g, g), v), kOneMinusB2));
-  w = __fsub_rn(w, __fdiv_rn(__fmul_rn(m, alpha), __fadd_rn(__fsqrt_rn(v), kAdamEps)));
+#pragma clang fp contract(off)
+  m = m + (g - m) * kOneMinusB1;
+  v = v + (g * g - v) * kOneMinusB2;
+  w = w - (m * alpha) / (sqrtf(v) + kAdamEps);
+}
+
+// g_total = (g_sparse - s*w) + two_l2*w with every product and sum rounded once.
+__device__ __forceinline__ float grad_total(float gs, float s, float w, float two_l2) {
+#pragma clang fp contract(off)
+  return (gs - s * w) + two_l2 * w;
 }
 
 __device__ __forceinline__ float sigmoidf_stable(float y) {

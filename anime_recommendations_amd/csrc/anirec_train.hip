@@ -684,11 +684,10 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
           if (l == 0) a.rowmap[r] = 0;
         }
       }
-      // g_total = (sum coef*other - s*w) + 2*l2*w     (no contraction: fixed rounding)
-      g.x = __fadd_rn(__fsub_rn(g.x, __fmul_rn(s, w.x)), __fmul_rn(a.two_l2, w.x));
-      g.y = __fadd_rn(__fsub_rn(g.y, __fmul_rn(s, w.y)), __fmul_rn(a.two_l2, w.y));
-      g.z = __fadd_rn(__fsub_rn(g.z, __fmul_rn(s, w.z)), __fmul_rn(a.two_l2, w.z));
-      g.w = __fadd_rn(__fsub_rn(g.w, __fmul_rn(s, w.w)), __fmul_rn(a.two_l2, w.w));
+      g.x = grad_total(g.x, s, w.x, a.two_l2);
+      g.y = grad_total(g.y, s, w.y, a.two_l2);
+      g.z = grad_total(g.z, s, w.z, a.two_l2);
+      g.w = grad_total(g.w, s, w.w, a.two_l2);
       adam_elem(w.x, m.x, v.x, g.x, alpha);
       adam_elem(w.y, m.y, v.y, g.y, alpha);
       adam_elem(w.z, m.z, v.z, g.z, alpha);

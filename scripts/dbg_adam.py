@@ -1,0 +1,24 @@
+import numpy as np, torch, sys
+sys.path.insert(0, ".")
+from anime_recommendations_amd import ops
+from oracle import anirec_oracle as orc
+rng = np.random.default_rng(5)
+n = 1 << 18
+w = rng.normal(0, 0.05, n).astype(np.float32)
+m = rng.normal(0, 1e-5, n).astype(np.float32)
+v = (rng.normal(0, 1e-5, n) ** 2).astype(np.float32)
+g = rng.normal(0, 1e-4, n).astype(np.float32)
+alpha = orc.adam_alpha(4.2e-5, 1234)
+w0, m0, v0 = w.copy(), m.copy(), v.copy()
+tw, tm, tv, tg = (torch.from_numpy(x.copy()).cuda() for x in (w, m, v, g))
+ops.adam_flat(tw, tm, tv, tg, alpha)
+torch.cuda.synchronize()
+orc.adam_update(w, m, v, g, alpha)
+for name, a, b in (("w", tw.cpu().numpy(), w), ("m", tm.cpu().numpy(), m), ("v", tv.cpu().numpy(), v)):
+    bad = np.nonzero(a != b)[0]
+    print(name, "mismatch", len(bad))
+    for i in bad[:5]:
+        print("  i", i, "gpu", a[i].hex() if hasattr(a[i], 'hex') else a[i], float(a[i]), "cpu", float(b[i]), "w0", w0[i], "m0", m0[i], "v0", v0[i], "g", g[i])
+# step-by-step numpy
+one_b1 = np.float32(1.0 - 0.9); one_b2 = np.float32(1.0-0.999)
+print(repr(one_b1), repr(one_b2), repr(alpha))

@@ -123,8 +123,11 @@ def test_train_steps_match_oracle(n_u, n_a, B, steps, zipf):
     V = eng.V.cpu().numpy()
     np.testing.assert_allclose(V[n_u:], st["vA"], atol=np.abs(st["vA"]).max() * 1e-4)
     h = st["head"]
-    for k in ("w", "b", "gamma", "beta"):
+    for k in ("w", "gamma", "beta"):
         assert abs(float(rec[k]) - float(h[k])) < tol, k
+    # d loss/d b == 0 analytically (BatchNorm removes the mean): its Adam step is driven by
+    # rounding noise in BOTH implementations, bounded by lr per step; it cannot change any output
+    assert abs(float(rec["b"]) - float(h["b"])) <= 2.05 * lr * len(starts)
     assert abs(rec["mov_mean"] - h["mov_mean"]) < 1e-6 and abs(rec["mov_var"] - h["mov_var"]) < 1e-6
     assert abs(rec["last_loss"] - mets[-1]["loss"]) < 5e-6
     loss_epoch = sum(float(m["loss"]) * c for m, c in zip(mets, counts)) / n
