@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""bench.py — training ratings/sec of the MI355X hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" is one optimiser step of the reference's model.fit (neural_network.py:210-217) over
+one batch of B = 10 000 ratings PER GPU (weak scaling: config.yaml:59 batch_size, scaled by
+the replica count as the reference's TPU branch intends, neural_network.py:176-177), on the
+synthetic S109M table shape (350 000 users x 18 000 anime, D = 128) — BASELINE.json configs[2],
+the configuration the 1/2/4/8-GPU metric is quoted on; the 7M-rating shape of configs[1]
+(15 000 x 17 560) is measured in the same run and reported under "also".
+
+Inputs (tables, Adam moments, the synthetic ratings, the schedule) are resident in HBM when
+the timed region starts; the timed region contains everything a step needs: batch sort/chunk
+prep, fwd, head, bwd, dense Adam — K steps, barrier + synchronize on both sides, max over ranks.
+
+Prints ONE JSON line (rank 0) with `roofline` (dense fused Adam kernel, HBM-bound) and
+`cpu_baseline` (the plain-C oracle port of the reference's CPU TensorFlow step, timed on this
+box's host cores; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (n_users, n_anime)  — SURVEY.md §8(d)
+    "s109m": (350_000, 18_000),
+    "s7m": (15_000, 17_560),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ADAM_BYTES_PER_ELEM = 28       # read W,m,v,g + write W,m,v
+FWD_BYTES_PER_RATING = 1048
+BWD_BYTES_PER_RATING = 2060
+RATING_PMF = [0.18, 0.005, 0.005, 0.01, 0.02, 0.05, 0.10, 0.20, 0.22, 0.13, 0.08]
+
+
+def synth_ratings(n_users, n_anime, n, device, seed=20260101):
+    """i.i.d. draws from the S7M/S109M marginal laws of SURVEY.md §8(d): users weighted by a
+    lognormal(ln 311, 0.35) activity, anime Zipf(s=1) over a fixed permutation, MAL-like ratings."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    act = torch.exp(torch.randn(n_users, generator=g, device=device) * 0.35 + float(np.log(311.0)))
+    ui = torch.multinomial(act, n, replacement=True, generator=g)
+    ranks = torch.arange(1, n_anime + 1, device=device, dtype=torch.float32)
+    perm = torch.randperm(n_anime, generator=g, device=device)
+    ai = perm[torch.multinomial(1.0 / ranks, n, replacement=True, generator=g)]
+    pmf = torch.tensor(RATING_PMF, device=device)
+    t = torch.multinomial(pmf, n, replacement=True, generator=g).to(torch.float32) / 10.0
+    return ui.to(torch.int32), ai.to(torch.int32), t
+
+
+def init_tables(n_users, n_anime, device, seed=7):
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    U = (torch.rand(n_users, 128, generator=g, device=device) - 0.5) * 0.1   # Keras 'uniform' init
+    A = (torch.rand(n_anime, 128, generator=g, device=device) - 0.5) * 0.1
+    return U, A
+
+
+def alphas_for(n_steps, lr=1e-5, t0=0):
+    from anime_recommendations_amd.schedule import adam_alpha
+    return [adam_alpha(lr, t0 + i + 1) for i in range(n_steps)]
+
+
+def run_single(workload, steps, warmup, batch, use_graph=True, cpu_baseline=True, quiet=False):
+    import torch
+    from anime_recommendations_amd.engine import TrainEngine
+    n_users, n_anime = WORKLOADS[workload]
+    dev = torch.device("cuda:0")
+    total_steps = warmup + 2 * steps          # timed region + instrumented per-kernel pass
+    ui, ai, t = synth_ratings(n_users, n_anime, total_steps * batch, dev)
+    U, A = init_tables(n_users, n_anime, dev)
+    eng = TrainEngine(n_users, n_anime, max_batch=batch, arena_steps=64)
+    eng.set_head(w=1.2)
+    eng.set_weights(U, A)
+    starts = np.arange(total_steps) * batch
+    eng.set_epoch(ui, ai, t, starts, np.full(total_steps, batch), alphas_for(total_steps))
+    if warmup:
+        eng.run(warmup, use_graph=use_graph)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.run(steps, use_graph=use_graph)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rec = eng.read_state()
+    assert int(rec["step_fwd"]) == warmup + steps and np.isfinite(rec["last_loss"])
+
+    # instrumented pass: the same K steps' worth of work, stage by stage, HIP events on the
+    # engine's stream around every launch of each kernel
+    evs = {k: [] for k in ("fwd", "head", "bwd", "adam")}
+    first = warmup + steps
+    done = 0
+    while done < steps:
+        blk = min(eng.arena_steps, steps - done)
+        eng.prep(first + done, blk)
+        for _ in range(blk):
+            for name in ("fwd", "head", "bwd", "adam"):
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(eng.stream)
+                getattr(eng, name)()
+                e1.record(eng.stream)
+                evs[name].append((e0, e1))
+        done += blk
+    eng.synchronize()
+    kern_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in evs.items()}
+    rows = n_users + n_anime
+    adam_bytes = ADAM_BYTES_PER_ELEM * rows * 128
+    adam_gbs = adam_bytes / (kern_ms["adam"] * 1e-3) / 1e9
+    out = {
+        "value": steps * batch / dt,
+        "ms_per_step": dt / steps * 1e3,
+        "loss": float(rec["last_loss"]),
+        "kernels_ms": kern_ms,
+        "roofline": {"kernel": "k_adam (dense fused Adam, both tables)", "bound": "hbm",
+                     "achieved": adam_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": adam_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": adam_bytes,
+                     "avg_launch_ms": kern_ms["adam"]},
+        "fwd_gbs": FWD_BYTES_PER_RATING * batch / (kern_ms["fwd"] * 1e-3) / 1e9,
+        "bwd_gbs": BWD_BYTES_PER_RATING * batch / (kern_ms["bwd"] * 1e-3) / 1e9,
+    }
+    eng.close()
+    del eng
+    torch.cuda.empty_cache()
+    if cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_port(n_users, n_anime, batch)
+    return out
+
+
+def cpu_baseline_port(n_users, n_anime, batch, budget_s=12.0):
+    """The reference's CPU TensorFlow step restated in C + OpenMP (oracle/anirec_oracle.c),
+    same table shape and batch size, timed on this box's host cores on a bounded sample."""
+    from oracle import anirec_oracle as orc
+    from oracle import c_oracle
+    rng = np.random.default_rng(7)
+    U = rng.uniform(-0.05, 0.05, (n_users, 128)).astype(np.float32)
+    A = rng.uniform(-0.05, 0.05, (n_anime, 128)).astype(np.float32)
+    st = orc.new_state(U, A, orc.new_head(w=1.2))
+    max_steps = 400
+    ui = rng.integers(0, n_users, max_steps * batch).astype(np.int32)
+    ranks = 1.0 / np.arange(1, n_anime + 1)
+    ai = rng.choice(n_anime, size=max_steps * batch, p=ranks / ranks.sum()).astype(np.int32)
+    t = (rng.choice(11, size=max_steps * batch, p=np.array(RATING_PMF) / sum(RATING_PMF)) / 10).astype(np.float32)
+    al = np.array([orc.adam_alpha(1e-5, i + 1) for i in range(max_steps)], np.float32)
+    t0 = time.perf_counter()
+    c_oracle.train_run(st, ui[:2 * batch], ai[:2 * batch], t[:2 * batch], batch, al[:2])
+    per = (time.perf_counter() - t0) / 2
+    n = int(max(3, min(max_steps - 2, budget_s / max(per, 1e-4))))
+    t0 = time.perf_counter()
+    c_oracle.train_run(st, ui[2 * batch:(2 + n) * batch], ai[2 * batch:(2 + n) * batch],
+                       t[2 * batch:(2 + n) * batch], batch, al[2:2 + n])
+    dt = time.perf_counter() - t0
+    return {"value": n * batch / dt, "unit": "ratings/s", "cores": c_oracle.max_threads(), "kind": "port",
+            "sample": "%d steps of %d ratings, %dx%d tables (plain-C/OpenMP restatement of the Keras "
+                      "CPU step; TensorFlow 2.12 is not installable offline)" % (n, batch, n_users, n_anime)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=10_000, help="ratings per GPU per step")
+    ap.add_argument("--workload", default="s109m", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 or args.gpus > 1:
+        from anime_recommendations_amd import dist_bench
+        return dist_bench.main(args)
+
+    res = run_single(args.workload, args.steps, args.warmup, args.batch, use_graph=not args.no_graph,
+                     cpu_baseline=not args.no_cpu_baseline)
+    n_users, n_anime = WORKLOADS[args.workload]
+    line = {
+        "metric": "training_ratings_per_sec", "value": res["value"], "unit": "ratings/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "%s: train step on %d users x %d anime tables, D=128, batch %d/GPU, "
+                               "L2 1e-4, Keras-2.12 Adam, lr=lrfn(0)=1e-5" % (args.workload, n_users, n_anime, args.batch),
+                   "global_batch": args.batch, "parallelism": "dp1"},
+        "roofline": res["roofline"],
+        "cpu_baseline": res.get("cpu_baseline"),
+        "kernels_ms": res["kernels_ms"],
+        "embed_fwd_GBps": res["fwd_gbs"], "embed_bwd_GBps": res["bwd_gbs"],
+        "final_loss": res["loss"],
+    }
+    if not args.no_also:
+        other = "s7m" if args.workload == "s109m" else "s109m"
+        r2 = run_single(other, args.steps, args.warmup, args.batch, use_graph=not args.no_graph,
+                        cpu_baseline=not args.no_cpu_baseline)
+        line["also"] = {other: {"value": r2["value"], "unit": "ratings/s", "ms_per_step": r2["ms_per_step"],
+                                "roofline": r2["roofline"], "kernels_ms": r2["kernels_ms"],
+                                "cpu_baseline": r2.get("cpu_baseline")}}
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()
