@@ -16,8 +16,9 @@ LIB_PATH = os.path.join(_PKG, "libanirec.so")
 DIM = 128
 MAX_BATCH = 16384
 CHUNK = 32
-ADAM_BLOCKS = 2048
+ADAM_BLOCKS = 8192
 MAX_TOPK = 128
+MAX_SEG = 16
 ABI_VERSION = 1
 
 

@@ -8,12 +8,13 @@
 //         unsorted_segment_sum densification of the gather gradients)
 //   fwd   half-wave per rating: coalesced 512-B gathers of U[ui], A[ai], three dot-128
 //         reductions by wavefront shuffles -> c, sum(u^2), sum(a^2)
-//   head  ONE workgroup: Dense(1) -> BatchNorm(batch stats) -> sigmoid -> BCE, closed-form
-//         backward to d loss/d c, Adam on the 4 scalars, moving stats, History metrics
+//   head  one workgroup per 256 ratings: batch mean/variance recomputed per workgroup,
+//         Dense(1) -> BatchNorm(batch stats) -> sigmoid -> BCE, d loss/d y, partial sums
 //   bwd   half-wave per chunk: weighted sum of the OTHER table's rows, accumulated in
 //         registers in a fixed order, one coalesced 512-B store per chunk (no float atomics)
 //   adam  half-wave per table row, dense: g = chunk sums - s*W + 2*l2*W, Keras-2.12 Adam,
-//         emits sum(W_new^2) partials for the L2 loss term.  HBM-bound: 24 B/element
+//         emits sum(W_new^2) partials for the L2 loss term; workgroup 0 finishes the step
+//         (Adam on the 4 head scalars, moving stats, History metrics, step cursor).  HBM-bound: 24 B/element
 //         (+512 B per touched row) instead of 28 because the dense gradient never exists.
 //
 // All kernels read the step index from device memory (anirec_state::step_fwd/step_bwd)
@@ -29,10 +30,20 @@ namespace anirec {
 // ------------------------------------------------------------------------------------
 // workspace layout
 // ------------------------------------------------------------------------------------
+// Step constants written by workgroup 0 of the head kernel, read by bwd and adam.
+struct StepPub {
+  int slot, n_total, n_head_blocks, step;
+  float alpha, mu, var, rs;
+  float w, b, gamma, beta;
+  float reg, l2, pad0, pad1;
+};
+
 struct TrainWs {
   int cap, capC, arena_steps;
   float *su, *sa;               // [cap] row square sums from fwd
-  float *coef, *selfu, *selfa;  // [cap] backward coefficients from head
+  float *dy;                    // [cap] d loss / d y from head
+  float *hpart;                 // [ANIREC_MAX_SEG * ceil(cap/256)][8] head partial sums
+  StepPub *pub;                 // step constants published by head workgroup 0
   float *regpart;               // [ANIREC_ADAM_BLOCKS]
   float *P;                     // [2*capC][128] chunk partial rows
   float *S;                     // [2*capC]      chunk self-coefficient sums
@@ -49,6 +60,8 @@ __host__ __device__ inline int chunk_capacity(int cap) {
 
 __host__ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+__host__ __device__ inline int packet_cap(int max_batch) { return (max_batch + 3) & ~3; }
+
 __host__ inline TrainWs carve(void *base, int cap, int arena_steps) {
   TrainWs w;
   w.cap = cap;
@@ -63,9 +76,9 @@ __host__ inline TrainWs carve(void *base, int cap, int arena_steps) {
   };
   w.su = (float *)take(sizeof(float) * cap);
   w.sa = (float *)take(sizeof(float) * cap);
-  w.coef = (float *)take(sizeof(float) * cap);
-  w.selfu = (float *)take(sizeof(float) * cap);
-  w.selfa = (float *)take(sizeof(float) * cap);
+  w.dy = (float *)take(sizeof(float) * cap);
+  w.hpart = (float *)take(sizeof(float) * 8 * ANIREC_MAX_SEG * (size_t)((cap + 255) / 256));
+  w.pub = (StepPub *)take(sizeof(StepPub));
   w.regpart = (float *)take(sizeof(float) * ANIREC_ADAM_BLOCKS);
   w.P = (float *)take(sizeof(float) * 2 * (size_t)w.capC * kDim);
   w.S = (float *)take(sizeof(float) * 2 * (size_t)w.capC);
@@ -361,16 +374,23 @@ __global__ __launch_bounds__(256) void k_fwd(FwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
-// head: everything that couples the batch (one workgroup)
+// head: Dense(1) -> BatchNorm(batch stats) -> sigmoid -> BCE, spread over many workgroups.
+// Every workgroup recomputes the batch mean/variance of z from all c (two-pass, no
+// transcendentals, 40 KB from L2), then does the sigmoid/log work of ITS 256 ratings and
+// leaves eight partial sums.  Workgroup 0 publishes the step constants for bwd / adam.
 // ------------------------------------------------------------------------------------
+constexpr int kHeadThreads = 256;
+constexpr int kHeadCols = 8;  // S1, S2, L, SE, sum dy*c, sum c, sum zh*c, sum zh
+
 struct HeadArgs {
-  anirec_state *state;
+  const anirec_state *state;
   const anirec_step *sched;
   const float *packets;  // n_seg packets
   size_t packet_floats;
-  int n_seg, my_seg, cap;
-  const float *su, *sa;  // local
-  float *coef, *selfu, *selfa;
+  int n_seg, my_seg, cap, arena_steps;
+  float *dy;             // [cap] d loss / d y of this rank's ratings
+  float *hpart;          // [n_seg*blocks_per_seg][8]
+  StepPub *pub;
   const float *regpart;
   float l2;
 };
@@ -379,154 +399,155 @@ __device__ __forceinline__ float bce_logits(float y, float t) {
   return fmaxf(y, 0.f) - y * t + log1pf(expf(-fabsf(y)));
 }
 
-__global__ __launch_bounds__(1024) void k_head(HeadArgs a) {
-  __shared__ float scratch[4 * 16];
-  const int tid = threadIdx.x;
-  anirec_state *st = a.state;
-  const int step = st->step_fwd;
-  const anirec_step sc = a.sched[step];
-  const float w = st->w, b = st->b, gamma = st->gamma, beta = st->beta;
+__device__ __forceinline__ int packet_count(const float *pk, int cap) {
+  return min(reinterpret_cast<const int32_t *>(pk + 2 * (size_t)packet_cap(cap))[0], cap);
+}
 
-  // L2 term: sum(W^2) of the weights this step reads (partials left by adam / init_reg)
-  float reg;
-  {
-    float r[1] = {0.f};
-    for (int i = tid; i < ANIREC_ADAM_BLOCKS; i += blockDim.x) r[0] += a.regpart[i];
-    block_sum<1>(r, scratch);
-    reg = r[0];
+// A packet's c values for the batch statistics: every 16-B load of the thread is issued before
+// the first use (a scalar strided loop serialises ~40 L2 round trips) and does not depend on
+// the packet's count word, so state, counts and values arrive in ONE memory round trip.
+constexpr int kHeadVec = ANIREC_MAX_BATCH / (4 * kHeadThreads);  // 16 float4 per thread at most
+
+struct SegVals {
+  float4 v[kHeadVec];
+};
+
+__device__ __forceinline__ void seg_load(const float *pk, int pcap, SegVals &x) {
+  const float4 *p4 = reinterpret_cast<const float4 *>(pk);
+#pragma unroll
+  for (int k = 0; k < kHeadVec; ++k) {
+    const int i4 = threadIdx.x + k * kHeadThreads;
+    x.v[k] = (i4 * 4 < pcap) ? p4[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+}
 
+template <bool kSecond>
+__device__ __forceinline__ float seg_stat(const SegVals &x, int cnt, float w, float b, float mu) {
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < kHeadVec; ++k) {
+    const int i = (threadIdx.x + k * kHeadThreads) * 4;
+    const float c4[4] = {x.v[k].x, x.v[k].y, x.v[k].z, x.v[k].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (i + j < cnt) {
+        const float z = c4[j] * w + b;
+        acc += kSecond ? (z - mu) * (z - mu) : z;
+      }
+    }
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(kHeadThreads) void k_head(HeadArgs a) {
+  __shared__ float scratch[kHeadCols * 16];
+  const int tid = threadIdx.x;
+  const anirec_state *st = a.state;
+  const int pcap = packet_cap(a.cap);
+  const int bps = (a.cap + kHeadThreads - 1) / kHeadThreads;  // blocks per segment
+  const int seg = blockIdx.x / bps;
+  const int i = (blockIdx.x % bps) * kHeadThreads + tid;
+
+  // ---- issue every independent load first --------------------------------------------
+  SegVals x0;
+  seg_load(a.packets, pcap, x0);  // segment 0 stays in registers for both passes
+  const float *mypk = a.packets + a.packet_floats * seg;
+  const float my_c = i < a.cap ? mypk[i] : 0.f;
+  const float my_t = i < a.cap ? mypk[pcap + i] : 0.f;
+  float4 rp[ANIREC_ADAM_BLOCKS / (4 * kHeadThreads)];
+  if (blockIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < ANIREC_ADAM_BLOCKS / (4 * kHeadThreads); ++k)
+      rp[k] = reinterpret_cast<const float4 *>(a.regpart)[tid + k * kHeadThreads];
+  }
+  const int step = st->step_fwd;
+  const float w = st->w, b = st->b, gamma = st->gamma, beta = st->beta;
+  int cnts[ANIREC_MAX_SEG];
   int n_total = 0;
-  for (int s = 0; s < a.n_seg; ++s) {
-    const float *pk = a.packets + a.packet_floats * s;
-    n_total += min(reinterpret_cast<const int32_t *>(pk + 2 * (size_t)a.cap)[0], a.cap);
+#pragma unroll
+  for (int s = 0; s < ANIREC_MAX_SEG; ++s) {
+    cnts[s] = s < a.n_seg ? packet_count(a.packets + a.packet_floats * s, a.cap) : 0;
+    n_total += cnts[s];
   }
   const float Bf = (float)n_total;
 
-  // pass 1: mean of z
-  float mu;
+  // ---- batch statistics of z over the whole (global) batch, redundantly per workgroup ----
+  float mu, var;
   {
-    float r[1] = {0.f};
-    for (int s = 0; s < a.n_seg; ++s) {
-      const float *pk = a.packets + a.packet_floats * s;
-      const int cnt = min(reinterpret_cast<const int32_t *>(pk + 2 * (size_t)a.cap)[0], a.cap);
-      for (int i = tid; i < cnt; i += blockDim.x) r[0] += pk[i] * w + b;
+    float r[1];
+    r[0] = seg_stat<false>(x0, cnts[0], w, b, 0.f);
+    for (int s = 1; s < a.n_seg; ++s) {
+      SegVals xs;
+      seg_load(a.packets + a.packet_floats * s, pcap, xs);
+      r[0] += seg_stat<false>(xs, packet_count(a.packets + a.packet_floats * s, a.cap), w, b, 0.f);
     }
     block_sum<1>(r, scratch);
     mu = r[0] / Bf;
-  }
-  // pass 2: biased variance (tf.nn.moments)
-  float var;
-  {
-    float r[1] = {0.f};
-    for (int s = 0; s < a.n_seg; ++s) {
-      const float *pk = a.packets + a.packet_floats * s;
-      const int cnt = min(reinterpret_cast<const int32_t *>(pk + 2 * (size_t)a.cap)[0], a.cap);
-      for (int i = tid; i < cnt; i += blockDim.x) {
-        const float d = (pk[i] * w + b) - mu;
-        r[0] += d * d;
-      }
+    r[0] = seg_stat<true>(x0, cnts[0], w, b, mu);
+    for (int s = 1; s < a.n_seg; ++s) {
+      SegVals xs;
+      seg_load(a.packets + a.packet_floats * s, pcap, xs);
+      r[0] += seg_stat<true>(xs, packet_count(a.packets + a.packet_floats * s, a.cap), w, b, mu);
     }
     block_sum<1>(r, scratch);
-    var = r[0] / Bf;
+    var = r[0] / Bf;  // biased (tf.nn.moments)
   }
   const float rs = 1.0f / sqrtf(var + kBnEps);
   const float inv = rs * gamma;
   const float shift = beta - mu * inv;
 
-  // pass 3: sigmoid, loss, first-level sums
-  float S1, S2, Lsum, SE;
-  {
-    float r[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < a.n_seg; ++s) {
-      const float *pk = a.packets + a.packet_floats * s;
-      const float *pt = pk + a.cap;
-      const int cnt = min(reinterpret_cast<const int32_t *>(pk + 2 * (size_t)a.cap)[0], a.cap);
-      for (int i = tid; i < cnt; i += blockDim.x) {
-        const float z = pk[i] * w + b;
-        const float t = pt[i];
-        const float y = z * inv + shift;
-        const float p = sigmoidf_stable(y);
-        const float dy = (p - t) / Bf;
-        const float zh = (z - mu) * rs;
-        r[0] += dy;
-        r[1] += dy * zh;
-        r[2] += bce_logits(y, t);
-        r[3] += (p - t) * (p - t);
-      }
-    }
-    block_sum<4>(r, scratch);
-    S1 = r[0];
-    S2 = r[1];
-    Lsum = r[2];
-    SE = r[3];
-  }
-  const float m1 = gamma * S1 / Bf;  // mean(d zhat)
-  const float m2 = gamma * S2 / Bf;  // mean(d zhat * zhat)
-
-  // pass 4: dz, dw, db; coefficients for this rank's ratings
-  float dW, dB;
-  {
-    float r[2] = {0.f, 0.f};
-    for (int s = 0; s < a.n_seg; ++s) {
-      const float *pk = a.packets + a.packet_floats * s;
-      const float *pt = pk + a.cap;
-      const int cnt = min(reinterpret_cast<const int32_t *>(pk + 2 * (size_t)a.cap)[0], a.cap);
-      for (int i = tid; i < cnt; i += blockDim.x) {
-        const float c = pk[i];
-        const float z = c * w + b;
-        const float t = pt[i];
-        const float y = z * inv + shift;
-        const float p = sigmoidf_stable(y);
-        const float dy = (p - t) / Bf;
-        const float zh = (z - mu) * rs;
-        const float dz = (dy * gamma - m1 - zh * m2) * rs;
-        r[0] += dz * c;
-        r[1] += dz;
-        if (s == a.my_seg) {
-          const float dc = dz * w;
-          const float su = a.su[i], sa = a.sa[i];
-          const float ru = 1.0f / sqrtf(fmaxf(su, kL2nEps));
-          const float ra = 1.0f / sqrtf(fmaxf(sa, kL2nEps));
-          a.coef[i] = dc * ru * ra;
-          a.selfu[i] = su >= kL2nEps ? dc * c * ru * ru : 0.f;
-          a.selfa[i] = sa >= kL2nEps ? dc * c * ra * ra : 0.f;
-        }
-      }
-    }
-    block_sum<2>(r, scratch);
-    dW = r[0];
-    dB = r[1];
-  }
-
-  if (tid == 0) {
-    const float alpha = sc.alpha;
-    float p4[4] = {w, b, gamma, beta};
-    const float g4[4] = {dW, dB, S2, S1};  // d w, d b, d gamma, d beta
+  // ---- this workgroup's 256 ratings ---------------------------------------------------------
+  int cnt = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float m = st->adam_m[k], v = st->adam_v[k];
-      adam_elem(p4[k], m, v, g4[k], alpha);
-      st->adam_m[k] = m;
-      st->adam_v[k] = v;
+  for (int s = 0; s < ANIREC_MAX_SEG; ++s)
+    if (s == seg) cnt = cnts[s];
+  float r[kHeadCols] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < cnt) {
+    const float c = my_c, t = my_t;
+    const float z = c * w + b;
+    const float y = z * inv + shift;
+    const float p = sigmoidf_stable(y);
+    const float dy = (p - t) / Bf;
+    const float zh = (z - mu) * rs;
+    r[0] = dy;
+    r[1] = dy * zh;
+    r[2] = bce_logits(y, t);
+    r[3] = (p - t) * (p - t);
+    r[4] = dy * c;
+    r[5] = c;
+    r[6] = zh * c;
+    r[7] = zh;
+    if (seg == a.my_seg) a.dy[i] = dy;
+  }
+  block_sum<kHeadCols>(r, scratch);
+  if (tid < kHeadCols) a.hpart[(size_t)blockIdx.x * kHeadCols + tid] = r[tid];
+
+  if (blockIdx.x == 0) {
+    // L2 term: sum(W^2) of the weights this step reads (partials left by adam / init_reg)
+    float q[1] = {0.f};
+#pragma unroll
+    for (int k = 0; k < ANIREC_ADAM_BLOCKS / (4 * kHeadThreads); ++k)
+      q[0] += (rp[k].x + rp[k].y) + (rp[k].z + rp[k].w);
+    block_sum<1>(q, scratch);
+    if (tid == 0) {
+      StepPub p;
+      p.slot = step % a.arena_steps;
+      p.n_total = n_total;
+      p.n_head_blocks = gridDim.x;
+      p.step = step;
+      p.alpha = a.sched[step].alpha;
+      p.mu = mu;
+      p.var = var;
+      p.rs = rs;
+      p.w = w;
+      p.b = b;
+      p.gamma = gamma;
+      p.beta = beta;
+      p.reg = q[0];
+      p.l2 = a.l2;
+      p.pad0 = p.pad1 = 0.f;
+      *a.pub = p;
     }
-    st->w = p4[0];
-    st->b = p4[1];
-    st->gamma = p4[2];
-    st->beta = p4[3];
-    st->mov_mean = st->mov_mean - (st->mov_mean - mu) * kBnDecay;
-    st->mov_var = st->mov_var - (st->mov_var - var) * kBnDecay;
-    st->reg_sumsq = reg;
-    st->bn_mu = mu;
-    st->bn_var = var;
-    const float loss = Lsum / Bf + a.l2 * reg;
-    st->last_loss = loss;
-    st->last_mse = SE / Bf;
-    st->loss_wsum += (double)loss * (double)n_total;
-    st->se_sum += (double)SE;
-    st->n_seen += (double)n_total;
-    st->step_bwd = step;
-    st->step_fwd = step + 1;
   }
 }
 
@@ -535,21 +556,35 @@ __global__ __launch_bounds__(1024) void k_head(HeadArgs a) {
 // ------------------------------------------------------------------------------------
 struct BwdArgs {
   const float *W;
-  const anirec_state *state;
+  const StepPub *pub;
+  const float *hpart;
   char *arena;
   size_t slot_bytes;
-  int cap, capC, arena_steps;
-  const float *coef, *selfu, *selfa;
+  int cap, capC;
+  const float *pk_c;     // this rank's c
+  const float *dy, *su, *sa;
   float *P, *S;
   int32_t *rowmap;
 };
 
 __global__ __launch_bounds__(256) void k_bwd(BwdArgs a) {
+  __shared__ float scratch[2 * 16];
+  const StepPub pub = *a.pub;
+  // mean(d zhat), mean(d zhat * zhat) from the head partials (fixed order)
+  float m[2] = {0.f, 0.f};
+  for (int k = threadIdx.x; k < pub.n_head_blocks; k += 256) {
+    m[0] += a.hpart[(size_t)k * kHeadCols + 0];
+    m[1] += a.hpart[(size_t)k * kHeadCols + 1];
+  }
+  block_sum<2>(m, scratch);
+  const float Bf = (float)pub.n_total;
+  const float m1 = pub.gamma * m[0] / Bf;
+  const float m2 = pub.gamma * m[1] / Bf;
+
   const int hw = blockIdx.x * 8 + (threadIdx.x >> 5);
   const int T = hw >= a.capC ? 1 : 0;
   const int c = hw - T * a.capC;
-  const int step = a.state->step_bwd;
-  Slot sl = slot_of(a.arena, a.slot_bytes, a.cap, a.capC, step % a.arena_steps);
+  Slot sl = slot_of(a.arena, a.slot_bytes, a.cap, a.capC, pub.slot);
   if (c >= sl.nchunks[T]) return;
   const int l = threadIdx.x & 31;
   const int4 rec = sl.chunks[T * a.capC + c];
@@ -559,8 +594,22 @@ __global__ __launch_bounds__(256) void k_bwd(BwdArgs a) {
   const int pos = rec.y + min(l, len - 1);
   const int i = sl.sidx[T * a.cap + pos];
   const int o = sl.oth[T * a.cap + pos];
-  float cf = a.coef[i];
-  float sf = (T == 0 ? a.selfu : a.selfa)[i];
+  float cf, sf;
+  {
+    // closed-form backward of BatchNorm + Dense(1) + normalised dot for rating i
+    const float ci = a.pk_c[i], dyi = a.dy[i];
+    const float su = a.su[i], sa = a.sa[i];
+    const float z = ci * pub.w + pub.b;
+    const float zh = (z - pub.mu) * pub.rs;
+    const float dz = (dyi * pub.gamma - m1 - zh * m2) * pub.rs;
+    const float dc = dz * pub.w;
+    const float ru = 1.0f / sqrtf(fmaxf(su, kL2nEps));
+    const float ra = 1.0f / sqrtf(fmaxf(sa, kL2nEps));
+    cf = dc * ru * ra;
+    const float sown = T == 0 ? su : sa;
+    const float rown = T == 0 ? ru : ra;
+    sf = sown >= kL2nEps ? dc * ci * rown * rown : 0.f;
+  }
   if (l >= len) {
     cf = 0.f;
     sf = 0.f;
@@ -629,7 +678,8 @@ __global__ __launch_bounds__(256) void k_densify(DensifyArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
-// adam: dense fused update of every table row
+// adam: dense fused update of every table row; workgroup 0 finishes the step (scalar
+// Adam, moving statistics, History metrics, cursor)
 // ------------------------------------------------------------------------------------
 struct AdamArgs {
   float *W, *M, *V;
@@ -637,72 +687,192 @@ struct AdamArgs {
   int32_t *rowmap;
   const float *P, *S;
   float *anime_grad;  // non-null: anime rows take their gradient from here (already reduced)
-  const anirec_state *state;
-  const anirec_step *sched;
+  anirec_state *state;
+  const StepPub *pub;
+  const float *hpart;
   float two_l2;
   float *regpart;
-  float fixed_alpha;  // used when sched == nullptr (init_reg passes alpha = 0 path separately)
 };
 
-template <bool kUpdate>
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+// streamed-once data: non-temporal loads/stores keep the three 188-MB streams from thrashing
+// L2/MALL lines that the gather kernels of the next step want (measured +6 % on the stream)
+__device__ __forceinline__ float4 ld_nt(const float4 *p) {
+  const f4v x = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));
+  return make_float4(x.x, x.y, x.z, x.w);
+}
+__device__ __forceinline__ void st_nt(float4 *p, const float4 &v) {
+  const f4v x = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(x, reinterpret_cast<f4v *>(p));
+}
+
+struct RowLoad {
+  float4 w, m, v, p0;  // p0: first chunk partial (zero if the row is untouched)
+  float s0;
+  int rm;
+};
+
+// issue every load of one row up front: W, M, V and — the row map word having been
+// prefetched one iteration earlier — the first chunk partial of a touched row
+template <bool kUpdate, bool kNT>
+__device__ __forceinline__ void row_issue(const AdamArgs &a, int r, int l, int rm, RowLoad &x) {
+  const size_t e = (size_t)r * kRowVec + l;
+  const float4 *Wp = reinterpret_cast<const float4 *>(a.W) + e;
+  x.w = kNT ? ld_nt(Wp) : *Wp;
+  x.rm = rm;
+  if (kUpdate) {
+    const float4 *Mp = reinterpret_cast<const float4 *>(a.M) + e;
+    const float4 *Vp = reinterpret_cast<const float4 *>(a.V) + e;
+    x.m = kNT ? ld_nt(Mp) : *Mp;
+    x.v = kNT ? ld_nt(Vp) : *Vp;
+    x.p0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    x.s0 = 0.f;
+    if (a.anime_grad != nullptr && r >= a.n_user_rows) {
+      const int ar = r - a.n_user_rows;
+      x.p0 = reinterpret_cast<const float4 *>(a.anime_grad)[(size_t)ar * kRowVec + l];
+      x.s0 = a.anime_grad[(size_t)a.n_anime_rows * kDim + ar];
+      x.rm = 0;
+    } else if (rm) {
+      const int first = (rm - 1) >> 10;
+      x.p0 = reinterpret_cast<const float4 *>(a.P)[(size_t)first * kRowVec + l];
+      x.s0 = a.S[first];
+    }
+  }
+}
+
+template <bool kNT>
+__device__ __forceinline__ void row_finish(const AdamArgs &a, int r, int l, float alpha, RowLoad &x) {
+  const size_t e = (size_t)r * kRowVec + l;
+  float4 g = x.p0;
+  float s = x.s0;
+  if (x.rm) {
+    const float4 *P4 = reinterpret_cast<const float4 *>(a.P);
+    const int first = (x.rm - 1) >> 10, nch = ((x.rm - 1) & 1023) + 1;
+    for (int c = first + 1; c < first + nch; ++c) {  // rows with > ANIREC_CHUNK contributions
+      const float4 p = P4[(size_t)c * kRowVec + l];
+      g.x += p.x;
+      g.y += p.y;
+      g.z += p.z;
+      g.w += p.w;
+      s += a.S[c];
+    }
+    if (l == 0) a.rowmap[r] = 0;
+  }
+  float4 w = x.w, m = x.m, v = x.v;
+  g.x = grad_total(g.x, s, w.x, a.two_l2);
+  g.y = grad_total(g.y, s, w.y, a.two_l2);
+  g.z = grad_total(g.z, s, w.z, a.two_l2);
+  g.w = grad_total(g.w, s, w.w, a.two_l2);
+  adam_elem(w.x, m.x, v.x, g.x, alpha);
+  adam_elem(w.y, m.y, v.y, g.y, alpha);
+  adam_elem(w.z, m.z, v.z, g.z, alpha);
+  adam_elem(w.w, m.w, v.w, g.w, alpha);
+  if (kNT) {
+    st_nt(reinterpret_cast<float4 *>(a.W) + e, w);
+    st_nt(reinterpret_cast<float4 *>(a.M) + e, m);
+    st_nt(reinterpret_cast<float4 *>(a.V) + e, v);
+  } else {
+    reinterpret_cast<float4 *>(a.W)[e] = w;
+    reinterpret_cast<float4 *>(a.M)[e] = m;
+    reinterpret_cast<float4 *>(a.V)[e] = v;
+  }
+  x.w = w;
+}
+
+template <bool kUpdate, bool kNT>
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
-  __shared__ float scratch[16];
+  __shared__ float scratch[kHeadCols * 16];
   const int l = threadIdx.x & 31;
   const int nhw = gridDim.x * 8;
   float alpha = 0.f;
-  if (kUpdate) alpha = a.sched[a.state->step_bwd].alpha;
-  float4 *W4 = reinterpret_cast<float4 *>(a.W);
-  float4 *M4 = reinterpret_cast<float4 *>(a.M);
-  float4 *V4 = reinterpret_cast<float4 *>(a.V);
-  const float4 *P4 = reinterpret_cast<const float4 *>(a.P);
+  if (kUpdate) alpha = a.pub->alpha;
   float sq = 0.f;
-  for (int r = blockIdx.x * 8 + (threadIdx.x >> 5); r < a.n_rows; r += nhw) {
-    const size_t e = (size_t)r * kRowVec + l;
-    float4 w = W4[e];
+  int r = blockIdx.x * 8 + (threadIdx.x >> 5);
+  // two rows in flight per half-wave; the row-map words of the NEXT pair are fetched one
+  // iteration ahead so a touched row's chunk partial is requested together with W/M/V
+  int rm0 = 0, rm1 = 0;
+  if (kUpdate) {
+    if (r < a.n_rows) rm0 = a.rowmap[r];
+    if (r + nhw < a.n_rows) rm1 = a.rowmap[r + nhw];
+  }
+  for (; r + nhw < a.n_rows; r += 2 * nhw) {
+    const int r1 = r + nhw;
+    RowLoad x0, x1;
+    row_issue<kUpdate, kNT>(a, r, l, rm0, x0);
+    row_issue<kUpdate, kNT>(a, r1, l, rm1, x1);
     if (kUpdate) {
-      float4 m = M4[e];
-      float4 v = V4[e];
-      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-      float s = 0.f;
-      if (a.anime_grad != nullptr && r >= a.n_user_rows) {
-        const int ar = r - a.n_user_rows;
-        float4 *G4 = reinterpret_cast<float4 *>(a.anime_grad);
-        g = G4[(size_t)ar * kRowVec + l];
-        s = a.anime_grad[(size_t)a.n_anime_rows * kDim + ar];
-      } else {
-        const int rm = a.rowmap[r];
-        if (rm) {
-          const int first = (rm - 1) >> 10, nch = ((rm - 1) & 1023) + 1;
-          for (int c = first; c < first + nch; ++c) {
-            const float4 p = P4[(size_t)c * kRowVec + l];
-            g.x += p.x;
-            g.y += p.y;
-            g.z += p.z;
-            g.w += p.w;
-            s += a.S[c];
-          }
-          if (l == 0) a.rowmap[r] = 0;
-        }
-      }
-      g.x = grad_total(g.x, s, w.x, a.two_l2);
-      g.y = grad_total(g.y, s, w.y, a.two_l2);
-      g.z = grad_total(g.z, s, w.z, a.two_l2);
-      g.w = grad_total(g.w, s, w.w, a.two_l2);
-      adam_elem(w.x, m.x, v.x, g.x, alpha);
-      adam_elem(w.y, m.y, v.y, g.y, alpha);
-      adam_elem(w.z, m.z, v.z, g.z, alpha);
-      adam_elem(w.w, m.w, v.w, g.w, alpha);
-      W4[e] = w;
-      M4[e] = m;
-      V4[e] = v;
+      const int rn0 = r + 2 * nhw, rn1 = r + 3 * nhw;
+      rm0 = rn0 < a.n_rows ? a.rowmap[rn0] : 0;
+      rm1 = rn1 < a.n_rows ? a.rowmap[rn1] : 0;
+      row_finish<kNT>(a, r, l, alpha, x0);
+      row_finish<kNT>(a, r1, l, alpha, x1);
     }
-    sq += w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
+    sq += x0.w.x * x0.w.x + x0.w.y * x0.w.y + x0.w.z * x0.w.z + x0.w.w * x0.w.w;
+    sq += x1.w.x * x1.w.x + x1.w.y * x1.w.y + x1.w.z * x1.w.z + x1.w.w * x1.w.w;
+  }
+  if (r < a.n_rows) {
+    RowLoad x0;
+    row_issue<kUpdate, kNT>(a, r, l, rm0, x0);
+    if (kUpdate) row_finish<kNT>(a, r, l, alpha, x0);
+    sq += x0.w.x * x0.w.x + x0.w.y * x0.w.y + x0.w.z * x0.w.z + x0.w.w * x0.w.w;
   }
   // block partial of sum(W_new^2), fixed order
   sq = wave_sum(sq);
   if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = sq;
   __syncthreads();
   if (threadIdx.x == 0) a.regpart[blockIdx.x] = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+
+  if (kUpdate && blockIdx.x == 0) {
+    // finish the step: reduce the head partials, Adam on (w, b, gamma, beta), moving stats
+    const StepPub pub = *a.pub;
+    float h[kHeadCols];
+#pragma unroll
+    for (int k = 0; k < kHeadCols; ++k) h[k] = 0.f;
+    for (int blk = threadIdx.x; blk < pub.n_head_blocks; blk += 256) {
+#pragma unroll
+      for (int k = 0; k < kHeadCols; ++k) h[k] += a.hpart[(size_t)blk * kHeadCols + k];
+    }
+    block_sum<kHeadCols>(h, scratch);
+    if (threadIdx.x == 0) {
+      anirec_state *st = a.state;
+      const double n = (double)pub.n_total;
+      const double S1 = h[0], S2 = h[1], L = h[2], SE = h[3];
+      const double Sdc = h[4], Sc = h[5], Szc = h[6], Sz = h[7];
+      const double g = pub.gamma, rs = pub.rs;
+      const double m1 = g * S1 / n, m2 = g * S2 / n;
+      // sum dz*c and sum dz with dz = (gamma*dy - m1 - zh*m2)*rs, expanded over the batch sums
+      const float dW = (float)(rs * (g * Sdc - m1 * Sc - m2 * Szc));
+      const float dB = (float)(rs * (g * S1 - n * m1 - m2 * Sz));
+      float p4[4] = {pub.w, pub.b, pub.gamma, pub.beta};
+      const float g4[4] = {dW, dB, (float)S2, (float)S1};  // d w, d b, d gamma, d beta
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float mm = st->adam_m[k], vv = st->adam_v[k];
+        adam_elem(p4[k], mm, vv, g4[k], pub.alpha);
+        st->adam_m[k] = mm;
+        st->adam_v[k] = vv;
+      }
+      st->w = p4[0];
+      st->b = p4[1];
+      st->gamma = p4[2];
+      st->beta = p4[3];
+      const float mmean = st->mov_mean, mvar = st->mov_var;
+      st->mov_mean = mmean - (mmean - pub.mu) * kBnDecay;
+      st->mov_var = mvar - (mvar - pub.var) * kBnDecay;
+      st->reg_sumsq = pub.reg;
+      st->bn_mu = pub.mu;
+      st->bn_var = pub.var;
+      const float loss = (float)(L / n) + pub.l2 * pub.reg;
+      st->last_loss = loss;
+      st->last_mse = (float)(SE / n);
+      st->loss_wsum += (double)loss * n;
+      st->se_sum += SE;
+      st->n_seen += n;
+      st->step_bwd = pub.step;
+      st->step_fwd = pub.step + 1;
+    }
+  }
 }
 
 // flat Adam with an explicit gradient (unit-testable bit-exact stage)
@@ -771,7 +941,10 @@ __global__ __launch_bounds__(256) void k_eval(EvalArgs a) {
 __global__ __launch_bounds__(1024) void k_sum_regpart(anirec_state *st, const float *regpart) {
   __shared__ float scratch[16];
   float r[1] = {0.f};
-  for (int i = threadIdx.x; i < ANIREC_ADAM_BLOCKS; i += blockDim.x) r[0] += regpart[i];
+  for (int i = threadIdx.x; i < ANIREC_ADAM_BLOCKS / 4; i += blockDim.x) {
+    const float4 v = reinterpret_cast<const float4 *>(regpart)[i];
+    r[0] += (v.x + v.y) + (v.z + v.w);
+  }
   block_sum<1>(r, scratch);
   if (threadIdx.x == 0) st->reg_sumsq = r[0];
 }
@@ -797,7 +970,8 @@ static int check_desc(const anirec_train_desc *d) {
     return ANIREC_EINVAL;
   if (d->max_batch < 1 || d->max_batch > ANIREC_MAX_BATCH) return ANIREC_EINVAL;
   if (d->n_user_rows < 1 || d->n_anime_rows < 1 || d->arena_steps < 1) return ANIREC_EINVAL;
-  if (d->n_seg < 1 || d->my_seg < 0 || d->my_seg >= d->n_seg) return ANIREC_EINVAL;
+  if (d->n_seg < 1 || d->n_seg > ANIREC_MAX_SEG || d->my_seg < 0 || d->my_seg >= d->n_seg)
+    return ANIREC_EINVAL;
   if (d->anime_dense && !d->anime_grad) return ANIREC_EINVAL;
   if (d->workspace_bytes < anirec_train_workspace_bytes(d->max_batch, d->arena_steps))
     return ANIREC_EWORKSPACE;
@@ -819,8 +993,8 @@ static int launch_fwd(const anirec_train_desc *d, const TrainWs &w, hipStream_t 
   a.state = d->state;
   float *pk = packet_ptr(d, d->my_seg);
   a.pk_c = pk;
-  a.pk_t = pk + d->max_batch;
-  a.pk_count = reinterpret_cast<int32_t *>(pk + 2 * (size_t)d->max_batch);
+  a.pk_t = pk + packet_cap(d->max_batch);
+  a.pk_count = reinterpret_cast<int32_t *>(pk + 2 * (size_t)packet_cap(d->max_batch));
   a.su = w.su;
   a.sa = w.sa;
   a.cap = d->max_batch;
@@ -837,29 +1011,30 @@ static int launch_head(const anirec_train_desc *d, const TrainWs &w, hipStream_t
   a.n_seg = d->n_seg;
   a.my_seg = d->my_seg;
   a.cap = d->max_batch;
-  a.su = w.su;
-  a.sa = w.sa;
-  a.coef = w.coef;
-  a.selfu = w.selfu;
-  a.selfa = w.selfa;
+  a.arena_steps = d->arena_steps;
+  a.dy = w.dy;
+  a.hpart = w.hpart;
+  a.pub = w.pub;
   a.regpart = w.regpart;
   a.l2 = d->l2;
-  hipLaunchKernelGGL(k_head, dim3(1), dim3(1024), 0, s, a);
+  const int bps = (d->max_batch + kHeadThreads - 1) / kHeadThreads;
+  hipLaunchKernelGGL(k_head, dim3(bps * d->n_seg), dim3(kHeadThreads), 0, s, a);
   return (int)hipGetLastError();
 }
 
 static int launch_bwd(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
   BwdArgs a;
   a.W = d->W;
-  a.state = d->state;
+  a.pub = w.pub;
+  a.hpart = w.hpart;
   a.arena = w.arena;
   a.slot_bytes = w.slot_bytes;
   a.cap = w.cap;
   a.capC = w.capC;
-  a.arena_steps = w.arena_steps;
-  a.coef = w.coef;
-  a.selfu = w.selfu;
-  a.selfa = w.selfa;
+  a.pk_c = packet_ptr(d, d->my_seg);
+  a.dy = w.dy;
+  a.su = w.su;
+  a.sa = w.sa;
   a.P = w.P;
   a.S = w.S;
   a.rowmap = d->rowmap;
@@ -895,16 +1070,22 @@ static AdamArgs adam_args(const anirec_train_desc *d, const TrainWs &w) {
   a.S = w.S;
   a.anime_grad = d->anime_dense ? d->anime_grad : nullptr;
   a.state = d->state;
-  a.sched = d->sched;
+  a.pub = w.pub;
+  a.hpart = w.hpart;
   a.two_l2 = 2.0f * d->l2;
   a.regpart = w.regpart;
-  a.fixed_alpha = 0.f;
   return a;
 }
 
 static int launch_adam(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
   AdamArgs a = adam_args(d, w);
-  hipLaunchKernelGGL(k_adam<true>, dim3(ANIREC_ADAM_BLOCKS), dim3(256), 0, s, a);
+  // tables that overflow the 256-MiB Infinity Cache are streamed non-temporally; small ones
+  // (the 7M-rating shape: 50 MB of W+M+V) stay cache-resident between steps
+  const size_t table_bytes = (size_t)a.n_rows * kDim * 4 * 3;
+  if (table_bytes > ((size_t)192 << 20))
+    hipLaunchKernelGGL((k_adam<true, true>), dim3(ANIREC_ADAM_BLOCKS), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_adam<true, false>), dim3(ANIREC_ADAM_BLOCKS), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
 
@@ -914,7 +1095,8 @@ using namespace anirec;
 
 extern "C" {
 
-size_t anirec_packet_floats(int32_t max_batch) { return 2 * (size_t)max_batch + 4; }
+// c[pcap] | t[pcap] | {count,0,0,0}, pcap = max_batch rounded up to 4 floats (16-B aligned rows)
+size_t anirec_packet_floats(int32_t max_batch) { return 2 * (size_t)packet_cap(max_batch) + 4; }
 
 size_t anirec_train_workspace_bytes(int32_t max_batch, int32_t arena_steps) {
   if (max_batch < 1 || max_batch > ANIREC_MAX_BATCH || arena_steps < 1) return 0;
@@ -927,7 +1109,7 @@ int anirec_train_init_reg(const anirec_train_desc *d, void *stream) {
   TrainWs w = carve(d->workspace, d->max_batch, d->arena_steps);
   AdamArgs a = adam_args(d, w);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_adam<false>, dim3(ANIREC_ADAM_BLOCKS), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((k_adam<false, false>), dim3(ANIREC_ADAM_BLOCKS), dim3(256), 0, s, a);
   ANIREC_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(k_sum_regpart, dim3(1), dim3(1024), 0, s, d->state, w.regpart);
   return (int)hipGetLastError();
@@ -982,7 +1164,6 @@ int anirec_train_bwd(const anirec_train_desc *d, void *stream) {
 int anirec_train_adam(const anirec_train_desc *d, void *stream) {
   int rc = check_desc(d);
   if (rc) return rc;
-  if (!d->sched) return ANIREC_EINVAL;
   return launch_adam(d, carve(d->workspace, d->max_batch, d->arena_steps), (hipStream_t)stream);
 }
 

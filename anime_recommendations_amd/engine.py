@@ -259,8 +259,9 @@ def workspace_layout(max_batch, arena_steps):
     capC = (cap + cap // _lib.CHUNK + 2 + 3) & ~3
     off = 0
     lay = {"cap": cap, "capC": capC}
-    for name, nbytes in (("su", 4 * cap), ("sa", 4 * cap), ("coef", 4 * cap), ("selfu", 4 * cap),
-                         ("selfa", 4 * cap), ("regpart", 4 * _lib.ADAM_BLOCKS),
+    for name, nbytes in (("su", 4 * cap), ("sa", 4 * cap), ("dy", 4 * cap),
+                         ("hpart", 4 * 8 * _lib.MAX_SEG * ((cap + 255) // 256)), ("pub", 64),
+                         ("regpart", 4 * _lib.ADAM_BLOCKS),
                          ("P", 4 * 2 * capC * DIM), ("S", 4 * 2 * capC)):
         lay[name] = (off, nbytes)
         off += _align(nbytes)

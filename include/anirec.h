@@ -34,8 +34,9 @@ extern "C" {
 #define ANIREC_DIM 128          /* embedding width (floats) */
 #define ANIREC_MAX_BATCH 16384  /* ratings per rank per step handled by one sort workgroup */
 #define ANIREC_CHUNK 32         /* max gradient contributions summed by one half-wave */
-#define ANIREC_ADAM_BLOCKS 2048 /* grid of the dense Adam kernel == length of reg partials */
+#define ANIREC_ADAM_BLOCKS 8192 /* grid of the dense Adam kernel == length of reg partials */
 #define ANIREC_MAX_TOPK 128     /* k limit of the fused top-k kernels */
+#define ANIREC_MAX_SEG 16       /* max head packets (ranks of one node) */
 
 enum {
   ANIREC_OK = 0,
@@ -121,7 +122,8 @@ typedef struct anirec_train_desc {
   size_t workspace_bytes;
 } anirec_train_desc;
 
-/* floats in one head packet: c[max_batch], t[max_batch], 4 ints {count,0,0,0} */
+/* floats in one head packet: c[pcap], t[pcap], 4 ints {count,0,0,0}; pcap = max_batch rounded
+ * up to a multiple of 4 */
 size_t anirec_packet_floats(int32_t max_batch);
 size_t anirec_train_workspace_bytes(int32_t max_batch, int32_t arena_steps);
 
@@ -137,11 +139,13 @@ int anirec_train_prep(const anirec_train_desc *d, int32_t first_step, int32_t n_
 /* The four stages of one step.  They read the step index from state->step_fwd /
  * state->step_bwd so that a captured graph can be replayed for every step:
  *   fwd  : gather U[ui], A[ai]; c = <l2n(u), l2n(a)>      -> packet, su, sa
- *   head : Dense(1) + BatchNorm(batch stats) + sigmoid + BCE, closed-form backward to
- *          d loss / d c, Adam on the 4 scalars, moving stats, epoch metrics; step_fwd++
- *   bwd  : per-chunk weighted row sums of the OTHER table -> chunk partials (+rowmap)
- *   adam : dense fused Adam over every row of both tables, g = sparse + 2*l2*W,
- *          also emits sum(W_new^2) partials; step_bwd++                                  */
+ *   head : Dense(1) + BatchNorm(batch stats over ALL packets) + sigmoid + BCE,
+ *          d loss / d y per rating and the batch partial sums
+ *   bwd  : closed-form backward to d loss / d c, per-chunk weighted row sums of the OTHER
+ *          table -> chunk partials (+rowmap)
+ *   adam : dense fused Adam over every row of both tables, g = sparse + 2*l2*W, emits
+ *          sum(W_new^2) partials; then Adam on the 4 scalars, moving stats, epoch
+ *          metrics, step_fwd++                                                           */
 int anirec_train_fwd(const anirec_train_desc *d, void *stream);
 int anirec_train_head(const anirec_train_desc *d, void *stream);
 int anirec_train_bwd(const anirec_train_desc *d, void *stream);

@@ -1,0 +1,37 @@
+import sys
+sys.path.insert(0, ".")
+import numpy as np
+from oracle import anirec_oracle as orc
+from anime_recommendations_amd.engine import TrainEngine
+
+def problem(seed, n_u, n_a, n, zipf=1.2):
+    rng = np.random.default_rng(seed)
+    U = rng.uniform(-0.05, 0.05, (n_u, 128)).astype(np.float32)
+    A = rng.uniform(-0.05, 0.05, (n_a, 128)).astype(np.float32)
+    ui = rng.integers(0, n_u, n).astype(np.int64)
+    ai = ((rng.zipf(zipf, n) - 1) % n_a).astype(np.int64)
+    t = (rng.integers(0, 11, n) / 10).astype(np.float32)
+    return U, A, ui, ai, t
+
+U, A, ui, ai, t = problem(7, 50, 20, 512)
+U[3] = 0.0
+ai[:300] = 5
+ui[:40] = 3
+st = orc.new_state(U, A, orc.new_head(w=0.8))
+lr = 1e-5
+orc.train_step(st, ui, ai, t, lr)
+outs = []
+for rep in range(6):
+    eng = TrainEngine(50, 20, max_batch=512, arena_steps=8)
+    eng.set_head(w=0.8)
+    eng.set_weights(U, A)
+    eng.set_epoch(ui, ai, t, [0], [512], [orc.adam_alpha(lr, 1)])
+    eng.run(1, use_graph=False)
+    gU, gA = eng.U.cpu().numpy(), eng.A.cpu().numpy()
+    dU, dA = np.abs(gU - st["U"]), np.abs(gA - st["A"])
+    print(rep, "max dU %.3e at %s  max dA %.3e at %s" % (dU.max(), np.unravel_index(dU.argmax(), dU.shape), dA.max(), np.unravel_index(dA.argmax(), dA.shape)),
+          "rows>3e-8:", np.nonzero((dU > 3e-8).any(1))[0], np.nonzero((dA > 3e-8).any(1))[0])
+    outs.append((gU.copy(), gA.copy()))
+    eng.close()
+for k in range(1, 6):
+    print("rep", k, "bitwise == rep0:", (outs[k][0] == outs[0][0]).all(), (outs[k][1] == outs[0][1]).all())

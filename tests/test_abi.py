@@ -69,7 +69,7 @@ int main(void){
 
 
 def test_size_queries_need_no_gpu(lib):
-    assert lib.anirec_packet_floats(10000) == 20004
+    assert lib.anirec_packet_floats(10000) == 20004 and lib.anirec_packet_floats(10001) == 20012
     assert lib.anirec_train_workspace_bytes(10000, 8) > 10000 * 128 * 4
     assert lib.anirec_train_workspace_bytes(_lib.MAX_BATCH + 1, 8) == 0
     assert lib.anirec_topk_workspace_bytes(1000, 4) >= 4 * 1000 * 4

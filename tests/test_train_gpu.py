@@ -80,22 +80,41 @@ def test_forward_and_head_match_oracle():
     f, g, met = orc.grads(U, A, ui, ai, t, head)
     eng.synchronize()
     pk = eng.packets.cpu().numpy()
+    pc = (B + 3) & ~3
     np.testing.assert_allclose(pk[:B], f["c"], atol=3e-7)
-    np.testing.assert_array_equal(pk[B:2 * B], t)
-    assert pk[2 * B:2 * B + 1].view(np.int32)[0] == B
+    np.testing.assert_array_equal(pk[pc:pc + B], t)
+    assert pk[2 * pc:2 * pc + 1].view(np.int32)[0] == B
     np.testing.assert_allclose(read_ws(eng, "su")[:B], f["su"], rtol=1e-6)
     np.testing.assert_allclose(read_ws(eng, "sa")[:B], f["sa"], rtol=1e-6)
     eng.head()
+    dy = read_ws(eng, "dy")[:B]
+    dy_o = (f["p"] - t) / np.float32(B)
+    np.testing.assert_allclose(dy, dy_o, atol=np.abs(dy_o).max() * 2e-5)
+    nblk = (B + 255) // 256
+    hp = read_ws(eng, "hpart")[:nblk * 8].reshape(nblk, 8).astype(np.float64).sum(0)
+    zh = (f["z"] - f["mu"]) * f["r"]
+    assert abs(hp[0] - float(np.sum(dy_o, dtype=np.float64))) < 1e-7            # d beta
+    assert abs(hp[1] - float(np.sum(dy_o.astype(np.float64) * zh))) < 1e-7      # d gamma
+    assert abs(hp[2] / B - float(met["bce"])) < 2e-6
+    assert abs(hp[3] / B - float(met["mse"])) < 1e-6
+    pub = np.frombuffer(read_ws(eng, "pub", np.uint8).tobytes()[:56],
+                        dtype=[("i", "<i4", (4,)), ("f", "<f4", (10,))])[0]
+    assert list(pub["i"]) == [0, B, nblk, 0]
+    assert abs(pub["f"][1] - f["mu"]) < 1e-6 and abs(pub["f"][2] - f["var"]) < 1e-7
+    assert abs(pub["f"][8] - met["reg"]) / met["reg"] < 1e-6
+    # bwd + adam finish the step: scalar state and History metrics
+    eng.prep(0, 1)
+    eng.bwd()
+    eng.adam()
     rec = eng.read_state()
     assert abs(rec["bn_mu"] - f["mu"]) < 1e-6 and abs(rec["bn_var"] - f["var"]) < 1e-7
     assert abs(rec["last_loss"] - met["loss"]) < 2e-6
     assert abs(rec["last_mse"] - met["mse"]) < 1e-6
     assert abs(rec["reg_sumsq"] - met["reg"]) / met["reg"] < 1e-6
-    scale = np.abs(g["coef"]).max()
-    np.testing.assert_allclose(read_ws(eng, "coef")[:B], g["coef"], atol=scale * 2e-4)
-    np.testing.assert_allclose(read_ws(eng, "selfu")[:B], g["self_u"], atol=np.abs(g["self_u"]).max() * 2e-4)
-    np.testing.assert_allclose(read_ws(eng, "selfa")[:B], g["self_a"], atol=np.abs(g["self_a"]).max() * 2e-4)
     assert rec["step_fwd"] == 1 and rec["step_bwd"] == 0
+    # first Adam step on the scalars moves each by lr*sign(g) (up to epsilon)
+    assert abs((float(rec["w"]) - 1.2) + np.sign(float(g["w"])) * 1e-5) < 5e-7
+    assert abs((float(rec["gamma"]) - 1.0) + np.sign(float(g["gamma"])) * 1e-5) < 5e-7
     eng.close()
 
 
@@ -198,6 +217,7 @@ def test_zero_and_duplicate_rows_edge_cases():
     eng = _engine(U, A, 512, head_w=0.8)
     eng.set_epoch(ui, ai, t, [0], [512], [orc.adam_alpha(lr, 1)])
     eng.run(1, use_graph=False)
+    eng.synchronize()               # the engine works on its own stream
     np.testing.assert_allclose(eng.U.cpu().numpy(), st["U"], atol=3e-8)
     np.testing.assert_allclose(eng.A.cpu().numpy(), st["A"], atol=3e-8)
     eng.close()
