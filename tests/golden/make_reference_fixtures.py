@@ -36,6 +36,21 @@ def main():
     with open(os.path.join(OUT, "reference_output_formats.json"), "w") as f:
         json.dump(fmt, f, indent=1, ensure_ascii=False)
 
+    # the CLI surface of the four hot-path components: flag names and which are booleans
+    # (reference <c>/<c>.py argparse blocks + <c>/MLproject parameter lists)
+    import re
+    flags = {}
+    for c in ("neural_network", "similar_anime", "similar_users", "model_recs"):
+        src = open("/root/reference/%s/%s.py" % (c, c)).read()
+        found = re.findall(r'add_argument\(\s*"--(\w+)",\s*type=([^,]+),', src)
+        ml = open("/root/reference/%s/MLproject" % c).read()
+        params = re.findall(r"^      (\w+):\s*$", ml, flags=re.M)
+        flags[c] = {"flags": [n for n, _ in found],
+                    "bool_flags": [n for n, t in found if "strtobool" in t],
+                    "mlproject_parameters": params}
+    with open(os.path.join(OUT, "component_flags.json"), "w") as f:
+        json.dump(flags, f, indent=1)
+
 
 if __name__ == "__main__":
     main()

@@ -1,0 +1,171 @@
+"""GPU end-to-end test of the drop-in components: neural_network -> similar_anime ->
+similar_users -> model_recs run as subprocesses with the reference's flag sets, on a small
+synthetic data set, and their CSV outputs are checked against the reference's output formats
+(tests/golden/reference_output_formats.json) and against the oracle on the trained weights."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from oracle import anirec_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(comp, flags, cwd, env):
+    argv = [sys.executable, os.path.join(ROOT, comp, comp + ".py")]
+    for k, v in flags.items():
+        argv += ["--" + k, str(v)]
+    r = subprocess.run(argv, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    return r.stdout.decode()
+
+
+@pytest.fixture(scope="module")
+def pipeline(tmp_path_factory):
+    from anime_recommendations_amd import artifacts, data
+    work = tmp_path_factory.mktemp("pipe")
+    env = dict(os.environ, ANIREC_ARTIFACT_DIR=str(work / "store"), ANIREC_SEED="3")
+    os.environ["ANIREC_ARTIFACT_DIR"] = env["ANIREC_ARTIFACT_DIR"]
+    paths = data.write_synthetic_dataset(str(work / "data"), n_users=300, n_anime=500, n_ratings=40_000, seed=2)
+    artifacts.log_artifact("user_stats.parquet", paths["user_stats"], "parquet")
+    artifacts.log_artifact("all_anime.csv", paths["all_anime"], "raw_data")
+    artifacts.log_artifact("synopses.csv", paths["synopses"], "raw_data")
+    nn = dict(test_size=2000, TPU_INIT=False, embedding_size=128, kernel_initializer="he_normal",
+              activation_function="sigmoid", model_loss="binary_crossentropy", optimizer="Adam",
+              start_lr=1e-4, min_lr=1e-4, max_lr=5e-4, batch_size=2000, rampup_epochs=2, sustain_epochs=0,
+              exp_decay=0.8, weights_artifact="wandb_main_weights.h5", save_weights_only=True,
+              checkpoint_metric="val_loss", save_freq="epoch", mode="min", save_best_weights=True, verbose=1,
+              epochs=3, save_model=True, model_name="./wandb_anime_nn.h5",
+              input_data="user_stats.parquet:latest", project_name="anime_recommendations",
+              model_artifact="wandb_anime_nn.h5", history_csv="wandb_anime_nn_history.csv",
+              ID_emb_name="user_embedding", anime_emb_name="anime_embedding", merged_name="dot_product",
+              main_df_type="parquet", model_type="h5", history_type="history_csv", weights_type="h5",
+              model_metrics='["mse"]', l2_reg_factor=1e-4)
+    out = _run("neural_network", nn, str(work), env)
+    return dict(work=work, env=env, paths=paths, nn_out=out)
+
+
+def test_neural_network_component_outputs(pipeline, golden_dir):
+    work = pipeline["work"]
+    hist = pd.read_csv(work / "wandb_anime_nn_history.csv")
+    ref_cols = pd.read_csv(os.path.join(golden_dir, "anime_nn_history.csv")).columns.tolist()
+    assert hist.columns.tolist() == ref_cols                       # ,loss,mse,val_loss,val_mse,lr
+    assert len(hist) == 3 and np.isfinite(hist.to_numpy()).all()
+    assert np.allclose(hist["lr"], [np.float32(x) for x in (1e-4, 3e-4, 5e-4)])
+    assert hist["loss"].iloc[-1] < hist["loss"].iloc[0]            # it trains
+    assert os.path.exists(work / "history.json") and os.path.exists(work / "neural_network.log")
+    from anime_recommendations_amd import artifacts, weights_io
+    m = weights_io.load_model(artifacts.use_artifact("wandb_anime_nn.h5:latest"))
+    df = pd.read_parquet(pipeline["paths"]["user_stats"])
+    assert m["U"].shape == (df.user_id.nunique(), 128) and m["A"].shape == (df.anime_id.nunique(), 128)
+    assert list(m["user_ids"]) == df.user_id.unique().tolist()     # index contract
+    # the History's val columns equal the oracle's evaluation of the saved weights on the hold-out
+    from anime_recommendations_amd import data
+    table = data.encode_frame(df)
+    _, te = table.split(2000)
+    st = dict(U=m["U"], A=m["A"], head=orc.new_head(**m["head"]))
+    ev = orc.evaluate(st, table.user[te], table.anime[te], table.rating[te].astype(np.float32))
+    assert abs(float(ev["val_loss"]) - hist["val_loss"].iloc[-1]) < 2e-5
+    assert abs(float(ev["val_mse"]) - hist["val_mse"].iloc[-1]) < 1e-5
+
+
+def _common(pipeline):
+    return dict(project_name="anime_recommendations", model="wandb_anime_nn.h5:latest", model_type="h5",
+                main_df="user_stats.parquet:latest", main_df_type="parquet",
+                anime_df="all_anime.csv:latest", anime_df_type="raw_data",
+                ID_emb_name="user_embedding", anime_emb_name="anime_embedding")
+
+
+def test_similar_anime_component(pipeline, golden_dir):
+    from anime_recommendations_amd import artifacts, components as C, weights_io
+    work, env = pipeline["work"], pipeline["env"]
+    anime = pd.read_csv(pipeline["paths"]["all_anime"])
+    query = anime["Name"].iloc[17]
+    flags = dict(_common(pipeline), sypnopsis_df_type="raw_data", sypnopses_df="synopses.csv:latest",
+                 anime_query=query, a_query_number=10, random_anime=False,
+                 anime_rec_genres='[None, "Action", "Comedy"]', an_spec_genres=True,
+                 types='["TV", "Movie"]', spec_types=True, a_rec_type="csv", save_sim_anime=True)
+    _run("similar_anime", flags, str(work), env)
+    out = pd.read_csv(work / (C.clean(query) + ".csv"))
+    fmt = json.load(open(os.path.join(golden_dir, "reference_output_formats.json")))["anime_similar_to_SilentMobius.csv"]
+    assert out.columns.tolist() == fmt["columns"] and len(out) == fmt["n_rows"]
+    assert (np.diff(out["Similarity"]) <= 0).all() and query not in out["Name"].tolist()
+    assert out["Type"].isin(["TV", "Movie"]).all()
+    assert out["Genres"].str.contains("Action|Comedy").all()
+    # oracle: numpy row-norm + dot + filtered ranking on the saved weights
+    m = weights_io.load_model(artifacts.use_artifact("wandb_anime_nn.h5:latest"))
+    Wh = orc.rownorm(m["A"])
+    ids = np.asarray(m["anime_ids"])
+    q = int(np.nonzero(ids == anime["MAL_ID"].iloc[17])[0][0])
+    meta = anime.set_index("MAL_ID").reindex(ids)
+    keep = meta["Type"].isin(["TV", "Movie"]).to_numpy() & meta["Genres"].str.contains("Action|Comedy").to_numpy()
+    s64 = Wh.astype(np.float64) @ Wh[q].astype(np.float64)
+    oi, _ = orc.topk_desc(s64.astype(np.float32), 10, exclude=q, mask=keep)
+    gaps = np.abs(np.diff(np.sort(s64[keep])[::-1][:11]))
+    if gaps.min() > 1e-6:
+        assert out["Name"].tolist() == meta["Name"].to_numpy()[oi].tolist()
+    np.testing.assert_allclose(out["Similarity"].to_numpy(), s64[oi], atol=2e-6)
+
+
+def test_similar_users_component(pipeline, golden_dir):
+    from anime_recommendations_amd import artifacts, weights_io
+    work, env = pipeline["work"], pipeline["env"]
+    df = pd.read_parquet(pipeline["paths"]["user_stats"])
+    user = int(df.user_id.unique()[5])
+    flags = dict(_common(pipeline), sim_user_query=user, id_query_number=10, max_ratings=600,
+                 sim_random_user=False, num_faves=3, TV_only=True, sim_users_fn="similar_users.csv",
+                 sim_users_type="csv", ID_fn="user_id.csv", ID_type="csv", save_sim_locally=True)
+    _run("similar_users", flags, str(work), env)
+    out = pd.read_csv(work / ("User_%d.csv" % user))
+    fmt = json.load(open(os.path.join(golden_dir, "reference_output_formats.json")))["User_153695_similar_users.csv"]
+    assert out.columns.tolist() == fmt["columns"] and len(out) == fmt["n_rows"]
+    assert (np.diff(out["similarity"]) < 0).all() and user not in out["similar_users"].tolist()
+    assert pd.read_csv(work / ("%d.csv" % user))["User_ID"].tolist() == [user]
+    m = weights_io.load_model(artifacts.use_artifact("wandb_anime_nn.h5:latest"))
+    Wh = orc.rownorm(m["U"])
+    ids = np.asarray(m["user_ids"])
+    q = int(np.nonzero(ids == user)[0][0])
+    s64 = Wh.astype(np.float64) @ Wh[q].astype(np.float64)
+    s64[q] = -np.inf
+    o = np.argsort(-s64, kind="stable")[:10]
+    if np.abs(np.diff(s64[np.argsort(-s64, kind="stable")[:11]])).min() > 1e-6:
+        assert out["similar_users"].tolist() == ids[o].tolist()            # bit-exact neighbour ids
+    np.testing.assert_allclose(out["similarity"].to_numpy(), s64[o], atol=2e-6)
+
+
+def test_model_recs_component(pipeline, golden_dir):
+    from anime_recommendations_amd import artifacts, weights_io
+    work, env = pipeline["work"], pipeline["env"]
+    df = pd.read_parquet(pipeline["paths"]["user_stats"])
+    user = int(df.user_id.unique()[5])
+    flags = dict(main_df="user_stats.parquet:latest", main_df_type="parquet", project_name="anime_recommendations",
+                 anime_df="all_anime.csv:latest", anime_df_type="raw_data", sypnopsis_df="synopses.csv:latest",
+                 sypnopsis_df_type="raw_data", model="wandb_anime_nn.h5:latest", model_type="h5",
+                 model_user_query=user, random_user=False, model_recs_fn="model_recs.csv", save_model_recs=True,
+                 model_num_recs=10, anime_types='["TV", "Movie"]', specify_types=True,
+                 model_genres='["Action", "Comedy", None]', specify_genres=False, model_ID_flow=True,
+                 model_ID_conf=False, model_recs_type="csv", flow_ID="user_id.csv:latest", flow_ID_type="csv")
+    _run("model_recs", flags, str(work), env)
+    out = pd.read_csv(work / ("User_ID_%d_model_recs.csv" % user))
+    fmt = json.load(open(os.path.join(golden_dir, "reference_output_formats.json")))["User_ID_153695_model_recs.csv"]
+    assert out.columns.tolist() == fmt["columns"] and len(out) == fmt["n_rows"]
+    assert (np.diff(out["Prediction"]) <= 0).all() and out["Prediction"].between(0, 1).all()
+    assert out["Type"].isin(["TV", "Movie"]).all()
+    watched = set(df[df.user_id == user].anime_id)
+    assert not (set(out["anime_id"]) & watched)
+    m = weights_io.load_model(artifacts.use_artifact("wandb_anime_nn.h5:latest"))
+    ids = np.asarray(m["anime_ids"])
+    uq = int(np.nonzero(np.asarray(m["user_ids"]) == user)[0][0])
+    p = orc.predict_pairs(m["U"], m["A"], orc.new_head(**m["head"]), np.full(len(ids), uq), np.arange(len(ids)))
+    anime = pd.read_csv(pipeline["paths"]["all_anime"]).set_index("MAL_ID").reindex(ids)
+    keep = ~np.isin(ids, list(watched)) & anime["Type"].isin(["TV", "Movie"]).to_numpy()
+    oi, op = orc.topk_desc(p, 10, mask=keep)
+    np.testing.assert_allclose(out["Prediction"].to_numpy(), op, atol=1e-5)     # BASELINE bar
+    if np.abs(np.diff(np.sort(p[keep])[::-1][:11])).min() > 2e-6:
+        assert out["anime_id"].tolist() == ids[oi].tolist()
