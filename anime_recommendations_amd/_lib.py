@@ -41,9 +41,11 @@ STATE_DTYPE = np.dtype([
     ("step_fwd", "<i4"), ("step_bwd", "<i4"), ("pad0", "<i4"),
     ("loss_wsum", "<f8"), ("se_sum", "<f8"), ("n_seen", "<f8"),
     ("val_bce_sum", "<f8"), ("val_se_sum", "<f8"), ("val_n", "<f8"),
+    ("bce_wsum", "<f8"), ("reg_user_wsum", "<f8"), ("reg_anime_wsum", "<f8"),
+    ("reg_user_sumsq", "<f4"), ("reg_anime_sumsq", "<f4"),
 ], align=True)
 assert STEP_DTYPE.itemsize == 16
-assert STATE_DTYPE.itemsize == 136, STATE_DTYPE.itemsize
+assert STATE_DTYPE.itemsize == 168, STATE_DTYPE.itemsize
 
 
 class TrainDesc(C.Structure):

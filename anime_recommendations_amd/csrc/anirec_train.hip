@@ -35,7 +35,7 @@ struct StepPub {
   int slot, n_total, n_head_blocks, step;
   float alpha, mu, var, rs;
   float w, b, gamma, beta;
-  float reg, l2, pad0, pad1;
+  float reg_u, reg_a, l2, pad0;  // sum(U_local^2), sum(A^2) of the weights this step reads
 };
 
 struct TrainWs {
@@ -44,7 +44,7 @@ struct TrainWs {
   float *dy;                    // [cap] d loss / d y from head
   float *hpart;                 // [ANIREC_MAX_SEG * ceil(cap/256)][8] head partial sums
   StepPub *pub;                 // step constants published by head workgroup 0
-  float *regpart;               // [ANIREC_ADAM_BLOCKS]
+  float *regpart;               // [2][ANIREC_ADAM_BLOCKS]: user-row / anime-row sum(W^2) partials
   float *P;                     // [2*capC][128] chunk partial rows
   float *S;                     // [2*capC]      chunk self-coefficient sums
   // arena slot s: nchunks[2] (4 ints), sidx[2][cap], oth[2][cap], chunks[2][capC] (int4)
@@ -79,7 +79,7 @@ __host__ inline TrainWs carve(void *base, int cap, int arena_steps) {
   w.dy = (float *)take(sizeof(float) * cap);
   w.hpart = (float *)take(sizeof(float) * 8 * ANIREC_MAX_SEG * (size_t)((cap + 255) / 256));
   w.pub = (StepPub *)take(sizeof(StepPub));
-  w.regpart = (float *)take(sizeof(float) * ANIREC_ADAM_BLOCKS);
+  w.regpart = (float *)take(sizeof(float) * 2 * ANIREC_ADAM_BLOCKS);
   w.P = (float *)take(sizeof(float) * 2 * (size_t)w.capC * kDim);
   w.S = (float *)take(sizeof(float) * 2 * (size_t)w.capC);
   w.slot_bytes = align_up(16) + 2 * align_up(sizeof(int32_t) * 2 * (size_t)cap) +
@@ -454,10 +454,11 @@ __global__ __launch_bounds__(kHeadThreads) void k_head(HeadArgs a) {
   const float *mypk = a.packets + a.packet_floats * seg;
   const float my_c = i < a.cap ? mypk[i] : 0.f;
   const float my_t = i < a.cap ? mypk[pcap + i] : 0.f;
-  float4 rp[ANIREC_ADAM_BLOCKS / (4 * kHeadThreads)];
+  constexpr int kRegVec = 2 * ANIREC_ADAM_BLOCKS / (4 * kHeadThreads);  // user half then anime half
+  float4 rp[kRegVec];
   if (blockIdx.x == 0) {
 #pragma unroll
-    for (int k = 0; k < ANIREC_ADAM_BLOCKS / (4 * kHeadThreads); ++k)
+    for (int k = 0; k < kRegVec; ++k)
       rp[k] = reinterpret_cast<const float4 *>(a.regpart)[tid + k * kHeadThreads];
   }
   const int step = st->step_fwd;
@@ -524,11 +525,11 @@ __global__ __launch_bounds__(kHeadThreads) void k_head(HeadArgs a) {
 
   if (blockIdx.x == 0) {
     // L2 term: sum(W^2) of the weights this step reads (partials left by adam / init_reg)
-    float q[1] = {0.f};
+    float q[2] = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < ANIREC_ADAM_BLOCKS / (4 * kHeadThreads); ++k)
-      q[0] += (rp[k].x + rp[k].y) + (rp[k].z + rp[k].w);
-    block_sum<1>(q, scratch);
+    for (int k = 0; k < kRegVec; ++k)
+      q[k >= kRegVec / 2 ? 1 : 0] += (rp[k].x + rp[k].y) + (rp[k].z + rp[k].w);
+    block_sum<2>(q, scratch);
     if (tid == 0) {
       StepPub p;
       p.slot = step % a.arena_steps;
@@ -543,9 +544,10 @@ __global__ __launch_bounds__(kHeadThreads) void k_head(HeadArgs a) {
       p.b = b;
       p.gamma = gamma;
       p.beta = beta;
-      p.reg = q[0];
+      p.reg_u = q[0];
+      p.reg_a = q[1];
       p.l2 = a.l2;
-      p.pad0 = p.pad1 = 0.f;
+      p.pad0 = 0.f;
       *a.pub = p;
     }
   }
@@ -787,7 +789,7 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
   const int nhw = gridDim.x * 8;
   float alpha = 0.f;
   if (kUpdate) alpha = a.pub->alpha;
-  float sq = 0.f;
+  float sq = 0.f, sqa = 0.f;  // sum(W_new^2) over user rows / anime rows of this thread
   int r = blockIdx.x * 8 + (threadIdx.x >> 5);
   // two rows in flight per half-wave; the row-map words of the NEXT pair are fetched one
   // iteration ahead so a touched row's chunk partial is requested together with W/M/V
@@ -808,20 +810,31 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
       row_finish<kNT>(a, r, l, alpha, x0);
       row_finish<kNT>(a, r1, l, alpha, x1);
     }
-    sq += x0.w.x * x0.w.x + x0.w.y * x0.w.y + x0.w.z * x0.w.z + x0.w.w * x0.w.w;
-    sq += x1.w.x * x1.w.x + x1.w.y * x1.w.y + x1.w.z * x1.w.z + x1.w.w * x1.w.w;
+    const float q0 = x0.w.x * x0.w.x + x0.w.y * x0.w.y + x0.w.z * x0.w.z + x0.w.w * x0.w.w;
+    const float q1 = x1.w.x * x1.w.x + x1.w.y * x1.w.y + x1.w.z * x1.w.z + x1.w.w * x1.w.w;
+    if (r < a.n_user_rows) sq += q0; else sqa += q0;
+    if (r1 < a.n_user_rows) sq += q1; else sqa += q1;
   }
   if (r < a.n_rows) {
     RowLoad x0;
     row_issue<kUpdate, kNT>(a, r, l, rm0, x0);
     if (kUpdate) row_finish<kNT>(a, r, l, alpha, x0);
-    sq += x0.w.x * x0.w.x + x0.w.y * x0.w.y + x0.w.z * x0.w.z + x0.w.w * x0.w.w;
+    const float q0 = x0.w.x * x0.w.x + x0.w.y * x0.w.y + x0.w.z * x0.w.z + x0.w.w * x0.w.w;
+    if (r < a.n_user_rows) sq += q0; else sqa += q0;
   }
   // block partial of sum(W_new^2), fixed order
   sq = wave_sum(sq);
-  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = sq;
+  sqa = wave_sum(sqa);
+  if ((threadIdx.x & 63) == 0) {
+    scratch[threadIdx.x >> 6] = sq;
+    scratch[4 + (threadIdx.x >> 6)] = sqa;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) a.regpart[blockIdx.x] = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+  if (threadIdx.x == 0) {
+    a.regpart[blockIdx.x] = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    a.regpart[ANIREC_ADAM_BLOCKS + blockIdx.x] = scratch[4] + scratch[5] + scratch[6] + scratch[7];
+  }
+  __syncthreads();
 
   if (kUpdate && blockIdx.x == 0) {
     // finish the step: reduce the head partials, Adam on (w, b, gamma, beta), moving stats
@@ -860,13 +873,19 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
       const float mmean = st->mov_mean, mvar = st->mov_var;
       st->mov_mean = mmean - (mmean - pub.mu) * kBnDecay;
       st->mov_var = mvar - (mvar - pub.var) * kBnDecay;
-      st->reg_sumsq = pub.reg;
+      const float reg = pub.reg_u + pub.reg_a;
+      st->reg_sumsq = reg;
+      st->reg_user_sumsq = pub.reg_u;
+      st->reg_anime_sumsq = pub.reg_a;
       st->bn_mu = pub.mu;
       st->bn_var = pub.var;
-      const float loss = (float)(L / n) + pub.l2 * pub.reg;
+      const float loss = (float)(L / n) + pub.l2 * reg;
       st->last_loss = loss;
       st->last_mse = (float)(SE / n);
       st->loss_wsum += (double)loss * n;
+      st->bce_wsum += L;
+      st->reg_user_wsum += (double)pub.reg_u * n;
+      st->reg_anime_wsum += (double)pub.reg_a * n;
       st->se_sum += SE;
       st->n_seen += n;
       st->step_bwd = pub.step;
@@ -939,14 +958,18 @@ __global__ __launch_bounds__(256) void k_eval(EvalArgs a) {
 }
 
 __global__ __launch_bounds__(1024) void k_sum_regpart(anirec_state *st, const float *regpart) {
-  __shared__ float scratch[16];
-  float r[1] = {0.f};
-  for (int i = threadIdx.x; i < ANIREC_ADAM_BLOCKS / 4; i += blockDim.x) {
+  __shared__ float scratch[2 * 16];
+  float r[2] = {0.f, 0.f};
+  for (int i = threadIdx.x; i < 2 * ANIREC_ADAM_BLOCKS / 4; i += blockDim.x) {
     const float4 v = reinterpret_cast<const float4 *>(regpart)[i];
-    r[0] += (v.x + v.y) + (v.z + v.w);
+    r[i >= ANIREC_ADAM_BLOCKS / 4 ? 1 : 0] += (v.x + v.y) + (v.z + v.w);
   }
-  block_sum<1>(r, scratch);
-  if (threadIdx.x == 0) st->reg_sumsq = r[0];
+  block_sum<2>(r, scratch);
+  if (threadIdx.x == 0) {
+    st->reg_user_sumsq = r[0];
+    st->reg_anime_sumsq = r[1];
+    st->reg_sumsq = r[0] + r[1];
+  }
 }
 
 __global__ __launch_bounds__(256) void k_gather_ratings(const int32_t *ui, const int32_t *ai,

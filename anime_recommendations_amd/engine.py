@@ -167,7 +167,8 @@ class TrainEngine:
 
     def reset_metrics(self):
         rec = self.read_state()
-        for k in ("loss_wsum", "se_sum", "n_seen", "val_bce_sum", "val_se_sum", "val_n"):
+        for k in ("loss_wsum", "se_sum", "n_seen", "val_bce_sum", "val_se_sum", "val_n", "bce_wsum",
+                  "reg_user_wsum", "reg_anime_wsum"):
             rec[k] = 0.0
         self.write_state(rec)
 
@@ -211,8 +212,9 @@ class TrainEngine:
             done += blk
         return n_steps
 
-    def evaluate(self, user_idx, anime_idx, rating):
-        """Validation pass (BN inference). Returns (val_loss, val_mse) with Keras semantics."""
+    def eval_sums(self, user_idx, anime_idx, rating):
+        """Validation pass (BN inference) over the given rows; returns the raw sums
+        (val_bce_sum, val_se_sum, val_n) and the L2 sums of the current tables."""
         dev = self.device
         u = torch.as_tensor(user_idx, device=dev).to(torch.int32).contiguous()
         a = torch.as_tensor(anime_idx, device=dev).to(torch.int32).contiguous()
@@ -220,13 +222,20 @@ class TrainEngine:
         rec = self.read_state()
         rec["val_bce_sum"] = rec["val_se_sum"] = rec["val_n"] = 0.0
         self.write_state(rec)
-        self.init_reg()  # reg_sumsq of the CURRENT weights
+        self.init_reg()  # reg sums of the CURRENT weights
         _lib.check(self.lib.anirec_eval(C.byref(self.desc), _lib.ptr(u), _lib.ptr(a), _lib.ptr(t),
                                         int(u.numel()), self._sp()), "anirec_eval")
         rec = self.read_state()
-        n = max(float(rec["val_n"]), 1.0)
-        val_loss = np.float32(rec["val_bce_sum"] / n) + np.float32(self.l2) * rec["reg_sumsq"]
-        return float(val_loss), float(rec["val_se_sum"] / n)
+        return {k: float(rec[k]) for k in ("val_bce_sum", "val_se_sum", "val_n", "reg_user_sumsq",
+                                           "reg_anime_sumsq", "reg_sumsq")}
+
+    def evaluate(self, user_idx, anime_idx, rating):
+        """Validation pass. Returns (val_loss, val_mse) with Keras semantics (val_loss includes
+        the whole-table L2 term, neural_network.py:216)."""
+        r = self.eval_sums(user_idx, anime_idx, rating)
+        n = max(r["val_n"], 1.0)
+        val_loss = np.float32(r["val_bce_sum"] / n) + np.float32(self.l2) * np.float32(r["reg_sumsq"])
+        return float(val_loss), float(r["val_se_sum"] / n)
 
     def epoch_metrics(self):
         rec = self.read_state()
@@ -261,7 +270,7 @@ def workspace_layout(max_batch, arena_steps):
     lay = {"cap": cap, "capC": capC}
     for name, nbytes in (("su", 4 * cap), ("sa", 4 * cap), ("dy", 4 * cap),
                          ("hpart", 4 * 8 * _lib.MAX_SEG * ((cap + 255) // 256)), ("pub", 64),
-                         ("regpart", 4 * _lib.ADAM_BLOCKS),
+                         ("regpart", 4 * 2 * _lib.ADAM_BLOCKS),
                          ("P", 4 * 2 * capC * DIM), ("S", 4 * 2 * capC)):
         lay[name] = (off, nbytes)
         off += _align(nbytes)

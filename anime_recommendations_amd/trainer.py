@@ -103,9 +103,12 @@ def fit(table: RatingTable, cfg: FitConfig, engine=None, log=print, device="cuda
     vt = torch.as_tensor(np.asarray(table.rating[te], np.float32), device=dev)
 
     B = min(cfg.batch_size, n_train)
-    starts = np.arange(0, n_train, B)
-    counts = np.minimum(B, n_train - starts)
+    # multi-GPU (dist.DistTrainEngine): each rank takes B ratings of a global batch of G*B
+    Bg = int(getattr(engine, "global_batch", B))
+    starts = np.arange(0, n_train, Bg)
+    counts = np.minimum(Bg, n_train - starts)
     n_steps = len(starts)
+    multi = hasattr(engine, "set_epoch_global")
     gen = torch.Generator(device=dev)
     hist = {"loss": [], "mse": [], "val_loss": [], "val_mse": [], "lr": []}
     best = np.inf if cfg.mode == "min" else -np.inf
@@ -116,9 +119,15 @@ def fit(table: RatingTable, cfg: FitConfig, engine=None, log=print, device="cuda
         lr = cfg.lr(epoch)
         gen.manual_seed(cfg.seed * 1_000_003 + epoch)
         perm = torch.randperm(n_train, generator=gen, device=dev)     # model.fit(shuffle=True)
-        eu, ea, et = ops.gather_ratings(ui, ai, rt, perm)
         alphas = schedule.adam_alphas(lr, t_global + 1, n_steps)
-        engine.set_epoch(eu, ea, et, starts, counts, alphas)
+        if multi:
+            import torch.distributed as dist
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                dist.broadcast(perm, src=0)                           # one shuffle for all ranks
+            engine.set_epoch_global(ui, ai, rt, perm, alphas)
+        else:
+            eu, ea, et = ops.gather_ratings(ui, ai, rt, perm)
+            engine.set_epoch(eu, ea, et, starts, counts, alphas)
         engine.reset_metrics()
         engine.run(n_steps, use_graph=cfg.use_graph)
         t_global += n_steps

@@ -181,7 +181,7 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 or args.gpus > 1:
+    if world > 1 or args.gpus > 1 or os.environ.get("ANIREC_FORCE_DIST") == "1":
         from anime_recommendations_amd import dist_bench
         return dist_bench.main(args)
 

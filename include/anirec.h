@@ -74,7 +74,7 @@ typedef struct anirec_state {
   float w, b, gamma, beta;
   float adam_m[4], adam_v[4]; /* Adam slots of the four scalars, same order */
   float mov_mean, mov_var;    /* BatchNormalization moving statistics */
-  float reg_sumsq;            /* sum(U^2)+sum(A^2) of the CURRENT tables (L2 term / lambda) */
+  float reg_sumsq;            /* sum(U_local^2)+sum(A^2) of the tables this step read (L2 term / lambda) */
   float bn_mu, bn_var;        /* batch statistics of the last training step */
   float last_loss, last_mse;  /* total loss (incl. L2) and mse of the last training step */
   int32_t step_fwd;           /* schedule cursor of the next fwd+head */
@@ -88,6 +88,10 @@ typedef struct anirec_state {
   double val_bce_sum; /* sum of per-row BCE */
   double val_se_sum;
   double val_n;
+  /* the same epoch loss split for user-partitioned multi-GPU runs: the caller adds the
+   * other ranks' user-table terms.  sums over steps of count * {bce, sum(U_local^2), sum(A^2)} */
+  double bce_wsum, reg_user_wsum, reg_anime_wsum;
+  float reg_user_sumsq, reg_anime_sumsq; /* split of reg_sumsq */
 } anirec_state;
 
 typedef struct anirec_train_desc {

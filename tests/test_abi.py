@@ -46,7 +46,7 @@ def test_struct_layouts_match_c(tmp_path):
 #include "anirec.h"
 int main(void){
   printf("%zu %zu %zu %zu\n", sizeof(anirec_step), sizeof(anirec_state), sizeof(anirec_train_desc), sizeof(anirec_head));
-  printf("%zu %zu %zu %zu\n", offsetof(anirec_state, step_fwd), offsetof(anirec_state, loss_wsum), offsetof(anirec_state, val_n), offsetof(anirec_state, reg_sumsq));
+  printf("%zu %zu %zu %zu\n", offsetof(anirec_state, step_fwd), offsetof(anirec_state, loss_wsum), offsetof(anirec_state, val_n), offsetof(anirec_state, reg_anime_sumsq));
   printf("%zu %zu %zu %zu\n", offsetof(anirec_train_desc, W), offsetof(anirec_train_desc, sched), offsetof(anirec_train_desc, packets), offsetof(anirec_train_desc, workspace_bytes));
   return 0; }
 '''
@@ -63,7 +63,7 @@ int main(void){
     assert out[2] == C.sizeof(_lib.TrainDesc)
     assert out[3] == C.sizeof(_lib.Head)
     assert out[4:8] == [S.fields["step_fwd"][1], S.fields["loss_wsum"][1], S.fields["val_n"][1],
-                        S.fields["reg_sumsq"][1]]
+                        S.fields["reg_anime_sumsq"][1]]
     D = _lib.TrainDesc
     assert out[8:12] == [D.W.offset, D.sched.offset, D.packets.offset, D.workspace_bytes.offset]
 

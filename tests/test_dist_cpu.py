@@ -1,0 +1,262 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU path: the user partition of every global
+batch, and the whole DistTrainEngine step protocol (fwd -> all_gather(packets) -> head -> bwd ->
+all_reduce(anime grad) -> adam) with the HIP stages replaced by a NumPy stand-in that speaks the
+same packet / anime_grad protocol.  The distributed result must equal the single-process oracle
+stepping on the GLOBAL batches."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from anime_recommendations_amd import _lib, schedule
+from anime_recommendations_amd.dist import DistTrainEngine, local_user_rows, partition_epoch
+from oracle import anirec_oracle as orc
+
+f32 = np.float32
+
+
+class NumpyStageEngine:
+    """Stage-level stand-in for engine.TrainEngine (tests only): same attributes, same packet
+    and anime_grad layouts as libanirec, arithmetic from the oracle's formulas."""
+
+    def __init__(self, n_user_rows, n_anime_rows, max_batch, l2=1e-4, arena_steps=64, device="cpu",
+                 n_seg=1, my_seg=0, anime_dense=False):
+        self.device = torch.device("cpu")
+        self.n_u, self.n_a, self.cap = n_user_rows, n_anime_rows, max_batch
+        self.pcap = (max_batch + 3) & ~3
+        self.packet_floats = 2 * self.pcap + 4
+        self.n_seg, self.my_seg, self.l2 = n_seg, my_seg, f32(l2)
+        self.arena_steps = arena_steps
+        self.packets = torch.zeros(n_seg * self.packet_floats, dtype=torch.float32)
+        self.anime_grad = torch.zeros(n_anime_rows * 128 + n_anime_rows, dtype=torch.float32)
+        self.stream = None
+        self.n_steps = 0
+        self.step = 0
+        self.acc = dict(bce_wsum=0.0, reg_user_wsum=0.0, reg_anime_wsum=0.0, se_sum=0.0, n_seen=0.0)
+
+    def set_head(self, w=1.0, **kw):
+        self.hd = orc.new_head(w=w)
+
+    def set_weights(self, U, A):
+        self.Uw = np.array(U, f32)
+        self.Aw = np.array(A, f32)
+        self.mU, self.vU = np.zeros_like(self.Uw), np.zeros_like(self.Uw)
+        self.mA, self.vA = np.zeros_like(self.Aw), np.zeros_like(self.Aw)
+
+    def reset_optimizer(self):
+        pass
+
+    def set_epoch(self, lu, la, lt, starts, counts, alphas, gcounts=None):
+        self.ep = (np.asarray(lu), np.asarray(la), np.asarray(lt, f32), starts, counts, np.asarray(alphas, f32))
+        self.n_steps = len(counts)
+        self.step = 0
+
+    def reset_metrics(self):
+        for k in self.acc:
+            self.acc[k] = 0.0
+
+    def prep(self, first, n):
+        pass
+
+    def synchronize(self):
+        pass
+
+    def _batch(self):
+        lu, la, lt, starts, counts, alphas = self.ep
+        s, c = int(starts[self.step]), int(counts[self.step])
+        return lu[s:s + c], la[s:s + c], lt[s:s + c], alphas[self.step]
+
+    def fwd(self):
+        lu, la, lt, _ = self._batch()
+        u, a = self.Uw[lu], self.Aw[la]
+        self.su, self.sa = np.sum(u * u, 1, dtype=f32), np.sum(a * a, 1, dtype=f32)
+        ru, ra = orc._inv_norm(self.su, f32), orc._inv_norm(self.sa, f32)
+        self.c = np.sum((u * ru[:, None]) * (a * ra[:, None]), 1, dtype=f32)
+        pk = self.packets.numpy()[self.my_seg * self.packet_floats:(self.my_seg + 1) * self.packet_floats]
+        n = len(lu)
+        pk[:n] = self.c
+        pk[self.pcap:self.pcap + n] = lt
+        pk[2 * self.pcap:2 * self.pcap + 1].view(np.int32)[0] = n
+
+    def head_stage(self):
+        cs, ts = [], []
+        P = self.packets.numpy()
+        for s in range(self.n_seg):
+            pk = P[s * self.packet_floats:(s + 1) * self.packet_floats]
+            n = int(pk[2 * self.pcap:2 * self.pcap + 1].view(np.int32)[0])
+            cs.append(pk[:n].copy())
+            ts.append(pk[self.pcap:self.pcap + n].copy())
+        self.offs = np.cumsum([0] + [len(x) for x in cs])
+        c, t = np.concatenate(cs), np.concatenate(ts)
+        h = self.hd
+        B = f32(len(c))
+        z = c * h["w"] + h["b"]
+        mu = np.mean(z, dtype=f32)
+        var = np.mean((z - mu) ** 2, dtype=f32)
+        r = f32(1) / np.sqrt(var + f32(orc.BN_EPS), dtype=f32)
+        inv = r * h["gamma"]
+        y = z * inv + (h["beta"] - mu * inv)
+        p = orc._sigmoid(y, f32)
+        dy = (p - t) / B
+        zh = (z - mu) * r
+        S1, S2 = np.sum(dy, dtype=f32), np.sum(dy * zh, dtype=f32)
+        dzh = dy * h["gamma"]
+        dz = (dzh - np.sum(dzh, dtype=f32) / B - zh * (np.sum(dzh * zh, dtype=f32) / B)) * r
+        self.g_head = np.array([np.sum(dz * c, dtype=f32), np.sum(dz, dtype=f32), S2, S1], f32)
+        self.glob = dict(mu=mu, var=var, n=len(c), bce=float(np.sum(orc.bce_from_logits(y, t), dtype=np.float64)),
+                         se=float(np.sum((p - t) ** 2, dtype=np.float64)))
+        lo, hi = self.offs[self.my_seg], self.offs[self.my_seg + 1]
+        self.dc = (dz * h["w"])[lo:hi]
+
+    def head(self):
+        self.head_stage()
+
+    def bwd(self):
+        lu, la, lt, _ = self._batch()
+        ru, ra = orc._inv_norm(self.su, f32), orc._inv_norm(self.sa, f32)
+        coef = self.dc * ru * ra
+        self_u = np.where(self.su >= f32(orc.L2N_EPS), self.dc * self.c * ru * ru, f32(0)).astype(f32)
+        self_a = np.where(self.sa >= f32(orc.L2N_EPS), self.dc * self.c * ra * ra, f32(0)).astype(f32)
+        self.gU = np.zeros_like(self.Uw)
+        np.add.at(self.gU, lu, coef[:, None] * self.Aw[la] - self_u[:, None] * self.Uw[lu])
+        G = self.anime_grad.numpy()
+        G[:] = 0
+        ga = G[:self.n_a * 128].reshape(self.n_a, 128)
+        np.add.at(ga, la, coef[:, None] * self.Uw[lu])
+        np.add.at(G[self.n_a * 128:], la, self_a)
+
+    def adam(self):
+        _, _, _, alpha = self._batch()
+        reg_u = float(np.sum(self.Uw.astype(np.float64) ** 2))
+        reg_a = float(np.sum(self.Aw.astype(np.float64) ** 2))
+        two = f32(2) * self.l2
+        G = self.anime_grad.numpy()
+        gA = G[:self.n_a * 128].reshape(self.n_a, 128) - G[self.n_a * 128:][:, None] * self.Aw + two * self.Aw
+        orc.adam_update(self.Uw, self.mU, self.vU, self.gU + two * self.Uw, alpha)
+        orc.adam_update(self.Aw, self.mA, self.vA, gA.astype(f32), alpha)
+        h = self.hd
+        hp = np.array([h["w"], h["b"], h["gamma"], h["beta"]], f32)
+        orc.adam_update(hp, h["m"], h["v"], self.g_head, alpha)
+        h["w"], h["b"], h["gamma"], h["beta"] = hp
+        h["mov_mean"] = f32(h["mov_mean"] - (h["mov_mean"] - self.glob["mu"]) * f32(0.01))
+        h["mov_var"] = f32(h["mov_var"] - (h["mov_var"] - self.glob["var"]) * f32(0.01))
+        n = self.glob["n"]
+        self.acc["bce_wsum"] += self.glob["bce"]
+        self.acc["reg_user_wsum"] += reg_u * n
+        self.acc["reg_anime_wsum"] += reg_a * n
+        self.acc["se_sum"] += self.glob["se"]
+        self.acc["n_seen"] += n
+        self.step += 1
+
+    def read_state(self):
+        d = dict(self.acc)
+        d.update({k: self.hd[k] for k in ("w", "b", "gamma", "beta", "mov_mean", "mov_var")})
+        return d
+
+    def eval_sums(self, lu, la, lt):
+        st = dict(U=self.Uw, A=self.Aw, head=self.hd)
+        lu, la, lt = np.asarray(lu), np.asarray(la), np.asarray(lt, f32)
+        out = dict(val_bce_sum=0.0, val_se_sum=0.0, val_n=float(len(lu)),
+                   reg_user_sumsq=float(np.sum(self.Uw.astype(np.float64) ** 2)),
+                   reg_anime_sumsq=float(np.sum(self.Aw.astype(np.float64) ** 2)))
+        if len(lu):
+            f = orc.forward(self.Uw, self.Aw, lu, la, self.hd, training=False)
+            out["val_bce_sum"] = float(np.sum(orc.bce_from_logits(f["y"], lt), dtype=np.float64))
+            out["val_se_sum"] = float(np.sum((f["p"] - lt) ** 2, dtype=np.float64))
+        return out
+
+    @property
+    def U(self):
+        return torch.from_numpy(self.Uw)
+
+    @property
+    def A(self):
+        return torch.from_numpy(self.Aw)
+
+    def close(self):
+        pass
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem():
+    rng = np.random.default_rng(11)
+    n_u, n_a, n = 61, 40, 3 * 128 - 37
+    U = rng.uniform(-0.05, 0.05, (n_u, 128)).astype(f32)
+    A = rng.uniform(-0.05, 0.05, (n_a, 128)).astype(f32)
+    ui = rng.integers(0, n_u, n)
+    ai = (rng.zipf(1.2, n) - 1) % n_a
+    t = (rng.integers(0, 11, n) / 10).astype(f32)
+    perm = rng.permutation(n)
+    return U, A, ui, ai, t, perm
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        U, A, ui, ai, t, perm = _problem()
+        B = 64                                   # per rank -> global batch 128
+        lr = 3e-5
+        tu, ta, tt, tp = (torch.from_numpy(np.asarray(x)) for x in (ui, ai, t, perm))
+        # 1) the partition: my share of each global batch, in order, local rows = u // world
+        lu, la, lt, starts, counts, gcounts = partition_epoch(tu, ta, tt, tp, B * world, rank, world)
+        for k, (s, c) in enumerate(zip(starts, counts)):
+            g = perm[k * B * world:(k + 1) * B * world]
+            mine = g[ui[g] % world == rank]
+            assert c == len(mine)
+            assert (lu[s:s + c].numpy() == ui[mine] // world).all() and (la[s:s + c].numpy() == ai[mine]).all()
+        assert list(gcounts) == [128, 128, len(perm) - 256]
+        # 2) the step protocol
+        eng = DistTrainEngine(U.shape[0], A.shape[0], B, l2=1e-4, device="cpu", engine_factory=NumpyStageEngine)
+        assert eng.n_local == local_user_rows(U.shape[0], rank, world)
+        eng.set_head(w=1.2)
+        eng.set_weights(U, A)
+        n_steps = len(counts)
+        eng.set_epoch_global(tu, ta, tt, tp, schedule.adam_alphas(lr, 1, n_steps))
+        eng.reset_metrics()
+        eng.run(n_steps)
+        loss, mse = eng.epoch_metrics()
+        vl, vm = eng.evaluate(tu[:100], ta[:100], tt[:100])
+        Ufull = eng.U.numpy()
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "dist.npz"), U=Ufull, A=eng.A.numpy(), loss=loss, mse=mse, vl=vl, vm=vm,
+                     w=eng.read_state()["w"], gamma=eng.read_state()["gamma"])
+        # replicas of the anime table stay bit-identical
+        a_all = [torch.empty_like(eng.A) for _ in range(world)]
+        dist.all_gather(a_all, eng.A.contiguous())
+        assert all((x == a_all[0]).all() for x in a_all)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_protocol_equals_single_process_oracle(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    d = np.load(tmp_path / "dist.npz")
+    U, A, ui, ai, t, perm = _problem()
+    st = orc.new_state(U, A, orc.new_head(w=1.2))
+    lr, Bg = 3e-5, 128
+    losses, ns = [], []
+    for k in range(0, len(perm), Bg):
+        g = perm[k:k + Bg]
+        met, _, _ = orc.train_step(st, ui[g], ai[g], t[g], lr)
+        losses.append(float(met["loss"]) * len(g))
+        ns.append(len(g))
+    tol = lr * 2e-3 * len(ns)
+    np.testing.assert_allclose(d["U"], st["U"], atol=tol)
+    np.testing.assert_allclose(d["A"], st["A"], atol=tol)
+    assert abs(float(d["w"]) - float(st["head"]["w"])) < tol and abs(float(d["gamma"]) - float(st["head"]["gamma"])) < tol
+    assert abs(float(d["loss"]) - sum(losses) / sum(ns)) < 5e-6
+    ev = orc.evaluate(st, ui[:100], ai[:100], t[:100])
+    assert abs(float(d["vl"]) - float(ev["val_loss"])) < 5e-6 and abs(float(d["vm"]) - float(ev["val_mse"])) < 1e-6
