@@ -30,11 +30,9 @@ def main(args):
         dist.init_process_group("nccl", device_id=dev)
     else:
         dist.init_process_group(backend)
-    try:
-        _run(args, rank, world, dev)
-    finally:
-        dist.barrier()
-        dist.destroy_process_group()
+    _run(args, rank, world, dev)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def _run(args, rank, world, dev):

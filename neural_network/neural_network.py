@@ -47,8 +47,27 @@ def go(args):
         rampup_epochs=int(args.rampup_epochs), sustain_epochs=int(args.sustain_epochs),
         exp_decay=float(args.exp_decay), monitor=args.checkpoint_metric, mode=args.mode,
         verbose=int(args.verbose), seed=int(os.environ.get("ANIREC_SEED", "0")))
-    res = trainer.fit(table, cfg, log=lambda s: (print(s), logger.info(s)))
+    # one process per GPU under torchrun (RANK/WORLD_SIZE set): ratings sharded by user, RCCL
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    engine, rank = None, 0
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        from anime_recommendations_amd.dist import DistTrainEngine
+        rank = int(os.environ["RANK"])
+        local = int(os.environ.get("LOCAL_RANK", rank))
+        torch.cuda.set_device(local)
+        if not dist.is_initialized():
+            dist.init_process_group(os.environ.get("ANIREC_DIST_BACKEND", "nccl"))
+        n_train = len(table) - cfg.test_size
+        engine = DistTrainEngine(table.n_users, table.n_anime, min(cfg.batch_size, max(1, n_train // world)),
+                                 l2=cfg.l2_reg_factor, device="cuda:%d" % local)
+        if rank != 0:
+            cfg.verbose = 0
+    res = trainer.fit(table, cfg, engine=engine, log=lambda s: (print(s), logger.info(s)))
     logger.info("model trained")
+    if rank != 0:
+        return res
 
     def stem(p):
         return os.path.splitext(p)[0] + ".safetensors"
