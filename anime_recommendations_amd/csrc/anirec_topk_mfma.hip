@@ -1,0 +1,496 @@
+// All-pairs cosine top-k on the gfx950 matrix cores.
+//
+// Replaces the reference's per-query  np.dot(W_hat, W_hat[q]) + np.argsort  (similar_anime.py:404-408,
+// similar_users.py:293-296) at BASELINE scale (every row a query, top-100 of 18 k / 350 k rows) without
+// ever materialising the n x n score matrix.
+//
+// Two kernels:
+//   k_cand    v_mfma_f32_32x32x16_f16 scores of 128 queries x all keys per workgroup (fp16 operands:
+//             the bf16 MFMA rate with 8x smaller rounding error); each query row keeps a candidate
+//             buffer in HBM/L2 and a running threshold + count in registers; a row's buffer is
+//             compacted (exact radix select of the M-th largest score) when it fills.  Because
+//             thresholds only rise, the buffer finally holds EVERY key whose MFMA score is >= theta.
+//   k_rerank  per query: tau = k-th largest MFMA score; MFMA scores of unit vectors are within
+//             eps = 2^-10 (+ fp32 accumulation) of the exact score, so the exact top-k is contained in
+//             {MFMA score >= tau - 2 eps}; if theta <= tau - 2 eps that set is complete -> its members
+//             are re-scored with the DEFINED fp32 fma chain and ranked (ties: ascending index).
+//             Otherwise the row is flagged and the caller re-runs it through the exact kernels.
+// Result: bit-exact neighbour lists at matrix-core speed.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <math.h>
+#include <stdlib.h>
+
+#include "anirec_dev.hpp"
+
+namespace anirec {
+
+constexpr int kBM = 128;        // query rows per workgroup (4 waves x 32 rows)
+constexpr int kBN = 128;        // keys per tile
+constexpr int kCap = 512;       // candidate buffer entries per query row (compacted when > kCap - kBN)
+// |fp16-operand MFMA score - fp32 fma-chain score| for unit-norm rows: each operand is rounded with
+// unit roundoff 2^-11 (fp16 has 11 significant bits: 8x tighter than bf16's 2^-8, at the same MFMA
+// rate), so a product is off by <= 2^-10 (1 + 2^-12) of |q_k w_k| and sum |q_k w_k| <= 1; fp16
+// subnormal components (< 6.1e-5) add <= 2^-25 * sum|w_k| <= 3.4e-7; the two fp32 accumulations add
+// <= 2 * 128 * 2^-24 = 1.6e-5; the threshold bias folded into the accumulator adds <= 5e-7.
+// 0.000977 + 0.000017 < 0.00101.
+constexpr float kEpsMfma = 0.00101f;
+constexpr float kThetaInit = -4.0f;  // below every cosine; finite so that (score - theta) stays finite
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint32_t f2key(float s) {  // order preserving, NaN -> 0 (never selected)
+  if (s != s) return 0u;
+  uint32_t u = __float_as_uint(s);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return u == 0u ? 1u : u;
+}
+__device__ __forceinline__ float key2f(uint32_t u) {
+  const uint32_t b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+  return __uint_as_float(b);
+}
+
+// fp32 [rows][128] (optionally gathered through `rows`) -> fp16, round to nearest even
+__global__ __launch_bounds__(256) void k_to_f16(const float *W, const int32_t *rows, int n,
+                                                _Float16 *out) {
+  const int l = threadIdx.x & 31;
+  const int nhw = gridDim.x * 8;
+  for (int r = blockIdx.x * 8 + (threadIdx.x >> 5); r < n; r += nhw) {
+    const int src = rows ? rows[r] : r;
+    const float4 x = reinterpret_cast<const float4 *>(W)[(size_t)src * kRowVec + l];
+    _Float16 o[4] = {(_Float16)x.x, (_Float16)x.y, (_Float16)x.z, (_Float16)x.w};
+    reinterpret_cast<uint2 *>(out)[(size_t)r * kRowVec + l] = *reinterpret_cast<uint2 *>(o);
+  }
+}
+
+struct CandArgs {
+  const uint4 *Qb;   // [nq][16] 16-B chunks of fp16 query rows
+  const uint4 *Wb;   // [n][16]
+  int nq, n, k_eff;
+  const uint8_t *keep;  // optional [n]
+  uint2 *cand;          // [nq][kCap] {score bits, key index}
+  int32_t *cnt;         // [nq]
+  float *theta;         // [nq]
+  int32_t *flags;       // [nq] bit0: buffer overflow (dense ties)
+};
+
+// Wave-cooperative compaction of one row's buffer.  tau = k_eff-th largest MFMA score seen so far is
+// a lower bound of the final one, so only keys with score >= tau - 2 eps can still matter: the new
+// threshold.  (one copy in the binary: called from a rare, non-unrolled loop)
+__device__ __noinline__ void compact_row(uint2 *cand_row, int c, int k_eff, int lane, int *out_cnt,
+                                         float *out_theta) {
+  uint2 en[kCap / 64];
+  uint32_t u[kCap / 64];
+#pragma unroll
+  for (int j = 0; j < kCap / 64; ++j) {
+    const int e = lane + 64 * j;
+    en[j] = e < c ? cand_row[e] : make_uint2(0u, 0u);
+    u[j] = e < c ? f2key(__uint_as_float(en[j].x)) : 0u;
+  }
+  uint32_t prefix = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t trial = prefix | (1u << bit);
+    int cge = 0;  // wave-uniform: ballots + scalar popcounts, no cross-lane shuffles
+#pragma unroll
+    for (int j = 0; j < kCap / 64; ++j) cge += __popcll(__ballot(u[j] >= trial));
+    if (cge >= k_eff) prefix = trial;
+  }
+  const float th = key2f(prefix) - 2.f * kEpsMfma;
+  int nc = 0;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int j = 0; j < kCap / 64; ++j) {
+    const bool kp = u[j] != 0u && __uint_as_float(en[j].x) >= th;
+    const unsigned long long m = __ballot(kp);
+    if (kp) cand_row[nc + __popcll(m & lt)] = en[j];  // nc + rank < c <= kCap
+    nc += __popcll(m);
+  }
+  *out_cnt = nc;
+  *out_theta = th;
+}
+
+template <int kDbg>  // 0: product; 1: no epilogue (timing experiments only)
+__global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
+  __shared__ __attribute__((aligned(16))) uint4 Ks[2][kBN * 16];  // 2 x 32 KB, XOR-swizzled chunks
+  __shared__ int cnt_s[kBM];
+  __shared__ float theta_s[kBM];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r32 = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.x * kBM;
+
+  // query fragments: A[row r32][k = 16*ks + 8*h + j]
+  f16x8 qa[8];
+  {
+    const int qrow = q0 + 32 * w + r32;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (qrow < a.nq) v = a.Qb[(size_t)qrow * 16 + 2 * ks + h];
+      qa[ks] = *reinterpret_cast<f16x8 *>(&v);
+    }
+  }
+  const int ntiles = (a.n + kBN - 1) / kBN;
+  uint4 stage[8];
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = tid + 256 * i;  // chunk id: key = c >> 4, chunk = c & 15
+      const int key = t * kBN + (c >> 4);
+      stage[i] = key < a.n ? a.Wb[(size_t)key * 16 + (c & 15)] : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = tid + 256 * i;
+      const int key = c >> 4, ch = c & 15;
+      Ks[buf][key * 16 + (ch ^ (key & 15))] = stage[i];
+    }
+  };
+  load_tile(0);
+  store_tile(0);
+  if (tid < kBM) {
+    cnt_s[tid] = 0;
+    theta_s[tid] = (q0 + tid < a.nq) ? kThetaInit : INFINITY;
+  }
+  __syncthreads();
+
+  // Accumulator register g of a 32x32 block belongs to query row (g&3) + 8(g>>2) + 4h of the
+  // wave's 32 rows: the rows are private to the wave, so their thresholds and buffer counts live
+  // in registers (replicated over the 32 lanes of a half-wave) — no LDS, no atomics in the loop.
+  float thr[16];
+  int cntr[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    thr[g] = theta_s[32 * w + (g & 3) + 8 * (g >> 2) + 4 * h];
+    cntr[g] = 0;
+  }
+  const uint32_t lt32 = (1u << r32) - 1u;
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) load_tile(t + 1);  // global loads in flight under the MFMAs
+    // C-in = -theta: the MFMA chain leaves (score - theta); a candidate is simply acc >= 0
+    f32x16 acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[cb][g] = -thr[g];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        const int key = cb * 32 + r32;
+        const uint4 bv = Ks[buf][key * 16 + ((2 * ks + h) ^ (key & 15))];
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[ks], *reinterpret_cast<const f16x8 *>(&bv),
+                                                         acc[cb], 0, 0, 0);
+      }
+    }
+    // next tile into the free LDS buffer NOW: the wait on its loads must not also wait for the
+    // candidate stores the epilogue is about to issue (vmcnt retires in order)
+    if (t + 1 < ntiles) store_tile(buf ^ 1);
+    if (kDbg == 1) {
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) asm volatile("" ::"v"(acc[cb]));
+    }
+    // epilogue: per-register ballots only where a quarter block has a candidate; ranks from
+    // popcounts, one 8-byte store per candidate
+#pragma unroll
+    for (int cb = 0; cb < (kDbg == 1 ? 0 : 4); ++cb) {
+      const int key = t * kBN + cb * 32 + r32;
+      bool ok = key < a.n;
+      if (ok && a.keep) ok = a.keep[key] != 0;
+      // hierarchical reject: one v_max3 + v_max + ballot per 4 accumulator registers (256 scores);
+      // at a pass rate of a few 1e-4 most quarters have no candidate
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const float mq = fmaxf(fmaxf(fmaxf(acc[cb][4 * qd], acc[cb][4 * qd + 1]), acc[cb][4 * qd + 2]),
+                               acc[cb][4 * qd + 3]);
+        if (__ballot(ok && mq >= 0.f)) {
+#pragma unroll
+          for (int gg = 0; gg < 4; ++gg) {
+            const int g = 4 * qd + gg;
+            const unsigned long long mk = __ballot(ok && acc[cb][g] >= 0.f);
+            if (mk) {  // wave-uniform
+              const uint32_t mh = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
+              const bool pass = (mh >> r32) & 1u;
+              const int pos = cntr[g] + __popc(mh & lt32);
+              if (pass && pos < kCap) {
+                const int rl = 32 * w + (g & 3) + 8 * (g >> 2) + 4 * h;
+                a.cand[(size_t)(q0 + rl) * kCap + pos] =
+                    make_uint2(__float_as_uint(acc[cb][g] + thr[g]), (uint32_t)key);
+              }
+              cntr[g] += __popc(mh);
+            }
+          }
+        }
+      }
+    }
+    // rows whose buffer could overflow during the next tile: compact now (rare)
+    {
+      int mx = cntr[0];
+#pragma unroll
+      for (int g = 1; g < 16; ++g) mx = max(mx, cntr[g]);
+      if (__ballot(mx > kCap - kBN)) {
+        if (r32 == 0) {
+#pragma unroll
+          for (int g = 0; g < 16; ++g) cnt_s[32 * w + (g & 3) + 8 * (g >> 2) + 4 * h] = cntr[g];
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's appends have landed
+        for (int rr = 0; rr < 32; ++rr) {
+          const int rl = 32 * w + rr;
+          const int c = cnt_s[rl];
+          if (c > kCap - kBN) {  // wave-uniform
+            int nc;
+            float nth;
+            compact_row(a.cand + (size_t)(q0 + rl) * kCap, min(c, kCap), a.k_eff, lane, &nc, &nth);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const bool ovf = nc > kCap - kBN;  // more keys inside the window than the buffer can take
+            if (lane == 0) {
+              cnt_s[rl] = nc;
+              theta_s[rl] = ovf ? INFINITY : nth;
+              if (ovf) a.flags[q0 + rl] |= 1;
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int rl = 32 * w + (g & 3) + 8 * (g >> 2) + 4 * h;
+          cntr[g] = cnt_s[rl];
+          thr[g] = theta_s[rl];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (r32 == 0) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int rl = 32 * w + (g & 3) + 8 * (g >> 2) + 4 * h;
+      if (q0 + rl < a.nq) {
+        a.cnt[q0 + rl] = min(cntr[g], kCap);
+        a.theta[q0 + rl] = thr[g];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// exact re-rank of one query row per wave
+// ------------------------------------------------------------------------------------
+struct RerankArgs {
+  const float *What;       // [n][128] fp32 normalised rows (keys)
+  const float *Qf;         // [nq][128] fp32 query rows (gathered) or nullptr -> What[qidx[row]]
+  const int32_t *qidx;     // [nq] index of the query row in the key table (self exclusion) or -1
+  int nq, n, k, k_eff;     // k_eff = k + 1 when the query itself must be dropped
+  int exclude_self;
+  const uint2 *cand;
+  const int32_t *cnt;
+  const float *theta;
+  int32_t *flags;          // bit1: incomplete window / too many survivors / too few candidates
+  int32_t *out_idx;        // [nq][k]
+  float *out_score;        // [nq][k]
+};
+
+constexpr int kMaxSurv = 256;
+
+__global__ __launch_bounds__(64) void k_rerank(RerankArgs a) {
+  __shared__ float qs[kDim];
+  __shared__ int32_t sidx[kMaxSurv];
+  __shared__ float sval[kMaxSurv];
+  const int lane = threadIdx.x;
+  const int row = blockIdx.x;
+  const size_t base = (size_t)row * kCap;
+  const int c = a.cnt[row];
+  const int qrow = a.qidx[row];
+  const int self = a.exclude_self ? qrow : -1;
+  // query row (fp32) into LDS
+  {
+    const float *q = a.Qf ? a.Qf + (size_t)row * kDim : a.What + (size_t)qrow * kDim;
+    qs[lane] = q[lane];
+    qs[lane + 64] = q[lane + 64];
+  }
+  float sc[kCap / 64];
+  int32_t id[kCap / 64];
+  uint32_t u[kCap / 64];
+#pragma unroll
+  for (int j = 0; j < kCap / 64; ++j) {
+    const int e = lane + 64 * j;
+    const uint2 en = e < c ? a.cand[base + e] : make_uint2(0u, 0u);
+    sc[j] = __uint_as_float(en.x);
+    id[j] = e < c ? (int32_t)en.y : -1;
+    u[j] = e < c ? f2key(sc[j]) : 0u;
+  }
+  bool bad = (a.flags[row] & 1) != 0;
+  const int kk = min(a.k_eff, a.n);
+  if (c < kk) bad = true;
+  // tau = kk-th largest bf16 score
+  uint32_t prefix = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t trial = prefix | (1u << bit);
+    int cge = 0;
+#pragma unroll
+    for (int j = 0; j < kCap / 64; ++j) cge += __popcll(__ballot(u[j] >= trial));
+    if (cge >= kk) prefix = trial;
+  }
+  const float tau = key2f(prefix);
+  const float lo = tau - 2.f * kEpsMfma;
+  if (!(a.theta[row] <= lo)) bad = true;  // the buffer is complete only down to theta
+  // survivors: bf16 score >= tau - 2 eps
+  int ns = 0;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int j = 0; j < kCap / 64; ++j) {
+    const bool kp = u[j] != 0u && sc[j] >= lo;
+    const unsigned long long m = __ballot(kp);
+    if (kp) {
+      const int pos = ns + __popcll(m & lt);
+      if (pos < kMaxSurv) sidx[pos] = id[j];
+    }
+    ns += __popcll(m);
+  }
+  if (ns > kMaxSurv) bad = true;
+  __syncthreads();
+  if (bad) {
+    if (lane == 0) a.flags[row] |= 2;
+    for (int i = lane; i < a.k; i += 64) {
+      a.out_idx[(size_t)row * a.k + i] = -1;
+      a.out_score[(size_t)row * a.k + i] = __uint_as_float(0x7FC00000u);
+    }
+    return;
+  }
+  // exact scores: k-ordered fp32 fma chain (the library's defined order)
+  for (int i = lane; i < ns; i += 64) {
+    const float4 *r4 = reinterpret_cast<const float4 *>(a.What + (size_t)sidx[i] * kDim);
+    float s = 0.f;
+#pragma unroll 8
+    for (int k4 = 0; k4 < kRowVec; ++k4) {
+      const float4 x = r4[k4];
+      s = __fmaf_rn(x.x, qs[4 * k4 + 0], s);
+      s = __fmaf_rn(x.y, qs[4 * k4 + 1], s);
+      s = __fmaf_rn(x.z, qs[4 * k4 + 2], s);
+      s = __fmaf_rn(x.w, qs[4 * k4 + 3], s);
+    }
+    sval[i] = s;
+  }
+  __syncthreads();
+  // rank by (score desc, index asc); the query itself is dropped
+  for (int i = lane; i < ns; i += 64) {
+    const int mi = sidx[i];
+    if (mi == self) continue;
+    const float ms = sval[i];
+    int rank = 0;
+    for (int j = 0; j < ns; ++j) {
+      const int oj = sidx[j];
+      if (oj == self) continue;
+      const float os = sval[j];
+      rank += (os > ms || (os == ms && oj < mi)) ? 1 : 0;
+    }
+    if (rank < a.k) {
+      a.out_idx[(size_t)row * a.k + rank] = mi;
+      a.out_score[(size_t)row * a.k + rank] = ms;
+    }
+  }
+  // fewer than k real neighbours (tiny tables): pad
+  int have = 0;
+  for (int i0 = 0; i0 < ns; i0 += 64) {
+    const int i = i0 + lane;
+    have += __popcll(__ballot(i < ns && sidx[i] != self));
+  }
+  for (int i = have + lane; i < a.k; i += 64) {
+    a.out_idx[(size_t)row * a.k + i] = -1;
+    a.out_score[(size_t)row * a.k + i] = __uint_as_float(0x7FC00000u);
+  }
+}
+
+__global__ void k_count_flags(const int32_t *flags, int nq, int32_t *count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nq && flags[i]) atomicAdd(count, 1);
+}
+
+}  // namespace anirec
+
+using namespace anirec;
+
+extern "C" {
+
+// workspace: Wb (n*256 B) | Qb (nq*256 B) | cand (nq*kCap*8) | cnt, theta (nq*4 each)
+size_t anirec_topk_mfma_workspace_bytes(int32_t n, int32_t nq) {
+  if (n < 1 || nq < 1) return 0;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  return al((size_t)n * 256) + al((size_t)nq * 256) + al((size_t)nq * kCap * 8) + 2 * al((size_t)nq * 4) + 256;
+}
+
+int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries, int32_t nq,
+                            const uint8_t *keep, int32_t exclude_self, int32_t k, int32_t *out_idx,
+                            float *out_score, int32_t *flags_out, void *workspace,
+                            size_t workspace_bytes, void *stream) {
+  if (!What || !queries || !out_idx || !out_score || !flags_out || !workspace) return ANIREC_EINVAL;
+  if (n < 1 || nq < 0 || k < 1 || k > ANIREC_MAX_TOPK - 1) return ANIREC_EINVAL;
+  if (nq == 0) return ANIREC_OK;
+  if (workspace_bytes < anirec_topk_mfma_workspace_bytes(n, nq)) return ANIREC_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  char *p = (char *)workspace;
+  _Float16 *Wb = (_Float16 *)p;
+  p += al((size_t)n * 256);
+  _Float16 *Qb = (_Float16 *)p;
+  p += al((size_t)nq * 256);
+  uint2 *cand = (uint2 *)p;
+  p += al((size_t)nq * kCap * 8);
+  int32_t *cnt = (int32_t *)p;
+  p += al((size_t)nq * 4);
+  float *theta = (float *)p;
+  p += al((size_t)nq * 4);
+  (void)p;
+  int b1 = (n + 7) / 8, b2 = (nq + 7) / 8;
+  if (b1 > 8192) b1 = 8192;
+  if (b2 > 8192) b2 = 8192;
+  hipLaunchKernelGGL(k_to_f16, dim3(b1), dim3(256), 0, s, What, nullptr, n, Wb);
+  hipLaunchKernelGGL(k_to_f16, dim3(b2), dim3(256), 0, s, What, queries, nq, Qb);
+  ANIREC_HIP_CHECK(hipGetLastError());
+  ANIREC_HIP_CHECK(hipMemsetAsync(flags_out, 0, (size_t)nq * 4, s));
+  CandArgs ca;
+  ca.Qb = (const uint4 *)Qb;
+  ca.Wb = (const uint4 *)Wb;
+  ca.nq = nq;
+  ca.n = n;
+  ca.k_eff = exclude_self ? k + 1 : k;
+  ca.keep = keep;
+  ca.cand = cand;
+  ca.cnt = cnt;
+  ca.theta = theta;
+  ca.flags = flags_out;
+  {
+    const char *dbg = getenv("ANIREC_TOPK_DEBUG");
+    const int mode = dbg ? atoi(dbg) : 0;
+    const dim3 grid((nq + kBM - 1) / kBM);
+    if (mode == 1)
+      hipLaunchKernelGGL(k_cand<1>, grid, dim3(256), 0, s, ca);
+    else
+      hipLaunchKernelGGL(k_cand<0>, grid, dim3(256), 0, s, ca);
+  }
+  ANIREC_HIP_CHECK(hipGetLastError());
+  RerankArgs ra;
+  ra.What = What;
+  ra.Qf = nullptr;
+  ra.qidx = queries;
+  ra.nq = nq;
+  ra.n = n;
+  ra.k = k;
+  ra.k_eff = exclude_self ? k + 1 : k;
+  ra.exclude_self = exclude_self ? 1 : 0;
+  ra.cand = cand;
+  ra.cnt = cnt;
+  ra.theta = theta;
+  ra.flags = flags_out;
+  ra.out_idx = out_idx;
+  ra.out_score = out_score;
+  // self exclusion is by key index; without it the query index is only used to fetch the row
+  hipLaunchKernelGGL(k_rerank, dim3(nq), dim3(64), 0, s, ra);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -88,6 +88,44 @@ def cosine_topk(What, queries, k, exclude_self=True, keep=None, workspace=None):
     return out_i, out_s
 
 
+def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=65536, fallback=True):
+    """cosine_topk on the matrix cores (bf16 MFMA candidates + exact fp32 re-rank); rows the
+    kernel could not prove complete are transparently re-run through the exact kernels.
+    Returns (idx, score, n_fallback)."""
+    _need_gpu()
+    lib = _lib.load()
+    assert What.is_cuda and What.dtype == torch.float32 and What.shape[1] == DIM
+    if not (1 <= k <= MAX_TOPK - 1):
+        raise ValueError("k must be in 1..%d" % (MAX_TOPK - 1))
+    dev, n = What.device, What.shape[0]
+    q = _i32(queries, dev)
+    nq = int(q.numel())
+    out_i = torch.empty(nq, k, dtype=torch.int32, device=dev)
+    out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
+    keep_t = None
+    if keep is not None:
+        keep_t = torch.as_tensor(keep, device=dev).to(torch.uint8).contiguous()
+    n_fb = 0
+    bq = min(nq, int(batch))
+    ws = torch.empty(int(lib.anirec_topk_mfma_workspace_bytes(n, max(bq, 1))), dtype=torch.uint8, device=dev)
+    flags = torch.empty(max(bq, 1), dtype=torch.int32, device=dev)
+    for q0 in range(0, nq, bq):
+        cnt = min(bq, nq - q0)
+        qs = q[q0:q0 + cnt]
+        _lib.check(lib.anirec_cosine_topk_mfma(_lib.ptr(What), n, _lib.ptr(qs), cnt, _lib.ptr(keep_t),
+                                               int(bool(exclude_self)), int(k), _lib.ptr(out_i[q0:q0 + cnt]),
+                                               _lib.ptr(out_s[q0:q0 + cnt]), _lib.ptr(flags), _lib.ptr(ws),
+                                               ws.numel(), _stream()), "anirec_cosine_topk_mfma")
+        bad = torch.nonzero(flags[:cnt], as_tuple=False).flatten()
+        if bad.numel():
+            n_fb += int(bad.numel())
+        if bad.numel() and fallback:
+            fi, fs = cosine_topk(What, qs[bad], k, exclude_self=exclude_self, keep=keep_t)
+            out_i[q0 + bad] = fi
+            out_s[q0 + bad] = fs
+    return out_i, out_s, n_fb
+
+
 def _head_struct(head):
     return _lib.Head(float(head["w"]), float(head["b"]), float(head["gamma"]), float(head["beta"]),
                      float(head["mov_mean"]), float(head["mov_var"]))

@@ -200,6 +200,17 @@ int anirec_cosine_topk(const float *What, int32_t n, const int32_t *queries, int
                        const uint8_t *keep, int32_t exclude_self, int32_t k, int32_t *out_idx,
                        float *out_score, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Same result as anirec_cosine_topk on the matrix cores: bf16 MFMA candidate scores for all
+ * keys with a rigorous error window, exact fp32 fma-chain re-rank of the survivors.
+ * flags[nq] (device) is non-zero for the rare query whose window could not be proven
+ * complete (dense ties / more than 256 survivors); its output row is -1/NaN and the caller
+ * re-runs it through anirec_cosine_topk.  k <= ANIREC_MAX_TOPK - 1. */
+size_t anirec_topk_mfma_workspace_bytes(int32_t n, int32_t nq);
+int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries, int32_t nq,
+                            const uint8_t *keep, int32_t exclude_self, int32_t k, int32_t *out_idx,
+                            float *out_score, int32_t *flags, void *workspace,
+                            size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------- *
  *  PREDICTION — replaces model.predict([user_arr, anime_arr]), model_recs/model_recs.py:394
  * ------------------------------------------------------------------------- */

@@ -1,5 +1,5 @@
 import numpy as np, torch, sys
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from anime_recommendations_amd import ops
 from oracle import anirec_oracle as orc
 rng = np.random.default_rng(5)

@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oracle import anirec_oracle as orc
 from anime_recommendations_amd.engine import TrainEngine

@@ -110,3 +110,53 @@ def test_predict_pairs_grid_topk_match_oracle():
         oi, op = orc.topk_desc(G[j], 10, mask=~watched[j])
         assert (ti[j] == oi).all()
         assert (tp[j] == op).all()
+
+
+@pytest.mark.parametrize("n,nq,k", [(1000, 1000, 10), (5000, 700, 100), (17560, 2048, 100), (333, 333, 127)])
+def test_mfma_topk_equals_exact_path_bitwise(n, nq, k):
+    """bf16-MFMA candidates + exact fp32 re-rank must reproduce the exact kernels' lists exactly."""
+    from anime_recommendations_amd import ops
+    rng = np.random.default_rng(10)
+    W = rng.normal(0, 0.05, (n, 128)).astype(np.float32)
+    W[11] = W[4]                               # exact score ties
+    W[12] = W[4]
+    W[20] = 0                                  # NaN row after normalisation
+    Wh = ops.rownorm(torch.from_numpy(W))
+    queries = rng.permutation(n)[:nq].astype(np.int32)
+    queries[:3] = [4, 11, 20]
+    ei, es = ops.cosine_topk(Wh, queries, k)
+    mi, ms, nfb = ops.cosine_topk_mfma(Wh, queries, k)
+    ei, es, mi, ms = (x.cpu().numpy() for x in (ei, es, mi, ms))
+    assert (mi == ei).all()
+    assert (ms == es)[~np.isnan(es)].all() and (np.isnan(ms) == np.isnan(es)).all()
+    assert nfb <= max(2, nq // 50)             # the NaN query row must fall back; hardly anything else
+
+
+def test_mfma_topk_masks_and_no_self_exclusion():
+    from anime_recommendations_amd import ops
+    rng = np.random.default_rng(11)
+    n = 4000
+    Wh = ops.rownorm(torch.from_numpy(rng.normal(0, 0.05, (n, 128)).astype(np.float32)))
+    keep = (rng.random(n) < 0.5).astype(np.uint8)
+    q = np.arange(0, n, 7, dtype=np.int32)
+    for excl in (True, False):
+        ei, es = ops.cosine_topk(Wh, q, 20, exclude_self=excl, keep=keep)
+        mi, ms, _ = ops.cosine_topk_mfma(Wh, q, 20, exclude_self=excl, keep=keep)
+        assert (mi.cpu().numpy() == ei.cpu().numpy()).all() and (ms.cpu().numpy() == es.cpu().numpy()).all()
+
+
+def test_mfma_topk_dense_cluster_falls_back_but_stays_exact():
+    """Hundreds of near-duplicate rows put >256 keys inside the 2-eps window: the kernel must
+    flag those queries (never return a wrong list) and the wrapper re-runs them exactly."""
+    from anime_recommendations_amd import ops
+    rng = np.random.default_rng(12)
+    n = 3000
+    W = rng.normal(0, 0.05, (n, 128)).astype(np.float32)
+    base = W[0].copy()
+    W[:600] = base + rng.normal(0, 1e-4, (600, 128)).astype(np.float32)
+    Wh = ops.rownorm(torch.from_numpy(W))
+    q = np.arange(0, 1200, 3, dtype=np.int32)
+    ei, es = ops.cosine_topk(Wh, q, 50)
+    mi, ms, nfb = ops.cosine_topk_mfma(Wh, q, 50)
+    assert nfb >= 100
+    assert (mi.cpu().numpy() == ei.cpu().numpy()).all() and (ms.cpu().numpy() == es.cpu().numpy()).all()
