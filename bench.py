@@ -119,6 +119,15 @@ def run_single(workload, steps, warmup, batch, use_graph=True, cpu_baseline=True
     rows = n_users + n_anime
     adam_bytes = ADAM_BYTES_PER_ELEM * rows * 128
     adam_gbs = adam_bytes / (kern_ms["adam"] * 1e-3) / 1e9
+    # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (PMC cannot
+    # be collected from inside this process); only quoted for the workload it was measured on
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_train_s109m.json")))
+        if workload == "s109m" and batch == 10_000:
+            traffic = pmc["k_adam"]["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     out = {
         "value": steps * batch / dt,
         "ms_per_step": dt / steps * 1e3,
@@ -126,7 +135,7 @@ def run_single(workload, steps, warmup, batch, use_graph=True, cpu_baseline=True
         "kernels_ms": kern_ms,
         "roofline": {"kernel": "k_adam (dense fused Adam, both tables)", "bound": "hbm",
                      "achieved": adam_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": adam_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "frac": adam_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": adam_bytes,
                      "avg_launch_ms": kern_ms["adam"]},
         "fwd_gbs": FWD_BYTES_PER_RATING * batch / (kern_ms["fwd"] * 1e-3) / 1e9,
