@@ -97,6 +97,8 @@ PROTOTYPES = {
     "anirec_predict_pairs": (C.c_int, [_vp, _vp, _vp, _vp, _i32, C.POINTER(Head), _vp, _vp]),
     "anirec_predict_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "anirec_predict_grid": (C.c_int, [_vp, _vp, _i32, _vp, _i32, C.POINTER(Head), _vp, _vp, _sz, _vp]),
+    "anirec_predict_mfma_workspace_bytes": (_sz, [_i32, _i32]),
+    "anirec_predict_grid_mfma": (C.c_int, [_vp, _vp, _i32, _vp, _i32, C.POINTER(Head), _vp, _vp, _sz, _vp]),
     "anirec_predict_topk": (C.c_int, [_vp, _vp, _i32, _vp, _i32, C.POINTER(Head), _vp, _i32, _vp,
                                       _vp, _vp, _sz, _vp]),
 }

@@ -162,6 +162,23 @@ def predict_grid(U, A, head, users):
     return out
 
 
+def predict_grid_mfma(U, A, head, users, out=None):
+    """predict_grid on the matrix cores (split-fp16 MFMA, ratings within 1e-5 of the fp32 path)."""
+    _need_gpu()
+    lib = _lib.load()
+    dev = U.device
+    us = _i32(users, dev)
+    n_a, n_q = A.shape[0], int(us.numel())
+    if out is None:
+        out = torch.empty(n_q, n_a, dtype=torch.float32, device=dev)
+    ws = torch.empty(int(lib.anirec_predict_mfma_workspace_bytes(n_a, max(n_q, 1))), dtype=torch.uint8, device=dev)
+    h = _head_struct(head)
+    _lib.check(lib.anirec_predict_grid_mfma(_lib.ptr(U), _lib.ptr(A), n_a, _lib.ptr(us), n_q, C.byref(h),
+                                            _lib.ptr(out), _lib.ptr(ws), ws.numel(), _stream()),
+               "anirec_predict_grid_mfma")
+    return out
+
+
 def predict_topk(U, A, head, users, k, watched_bits=None):
     """Top-k unwatched anime by predicted rating per user.  watched_bits: uint32/int32
     [n_users, ceil(n_anime/32)] (bit set = watched) or None."""

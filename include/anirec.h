@@ -234,6 +234,13 @@ int anirec_predict_grid(const float *U, const float *A, int32_t n_anime, const i
                         int32_t n_users, const anirec_head *head_host, float *out,
                         void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same grid on the matrix cores: rows are split x = hi + lo in fp16 and accumulated as
+ * hi*hi + hi*lo + lo*hi by v_mfma_f32_32x32x16_f16 (ratings within 1e-5 of the fp32 path). */
+size_t anirec_predict_mfma_workspace_bytes(int32_t n_anime, int32_t n_users);
+int anirec_predict_grid_mfma(const float *U, const float *A, int32_t n_anime, const int32_t *users,
+                             int32_t n_users, const anirec_head *head_host, float *out,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
 /* Per query user: top-k anime by descending predicted rating among anime whose
  * watched bit is clear.  watched: optional [n_users][ceil(n_anime/32)] bitmask words.
  * (model_recs.py:144-155 candidate set, :396 ranking, :451-454 cut). */

@@ -160,3 +160,21 @@ def test_mfma_topk_dense_cluster_falls_back_but_stays_exact():
     mi, ms, nfb = ops.cosine_topk_mfma(Wh, q, 50)
     assert nfb >= 100
     assert (mi.cpu().numpy() == ei.cpu().numpy()).all() and (ms.cpu().numpy() == es.cpu().numpy()).all()
+
+
+def test_predict_grid_mfma_within_1e5_of_oracle_and_fp32_path():
+    from anime_recommendations_amd import ops
+    rng = np.random.default_rng(13)
+    n_u, n_a = 900, 1777
+    U = rng.normal(0, 0.05, (n_u, 128)).astype(np.float32)
+    A = rng.normal(0, 0.05, (n_a, 128)).astype(np.float32)
+    A[5] *= 40.0                               # wide dynamic range of row norms
+    U[7] = 0.0                                 # zero row: l2_normalize clamps, c = 0
+    head = dict(w=1.3, b=0.1, gamma=0.9, beta=-0.2, mov_mean=0.05, mov_var=0.4)
+    tU, tA = torch.from_numpy(U).cuda(), torch.from_numpy(A).cuda()
+    users = np.concatenate([[7, 0, n_u - 1], rng.integers(0, n_u, 300)])
+    G = ops.predict_grid_mfma(tU, tA, head, users).cpu().numpy()
+    Gf = ops.predict_grid(tU, tA, head, users).cpu().numpy()
+    np.testing.assert_allclose(G, Gf, atol=3e-6)
+    Go = orc.predict_grid(U, A, orc.new_head(**head), users[:40])
+    np.testing.assert_allclose(G[:40], Go, atol=1e-5)      # BASELINE bar
