@@ -260,3 +260,34 @@ def test_two_rank_protocol_equals_single_process_oracle(tmp_path):
     assert abs(float(d["loss"]) - sum(losses) / sum(ns)) < 5e-6
     ev = orc.evaluate(st, ui[:100], ai[:100], t[:100])
     assert abs(float(d["vl"]) - float(ev["val_loss"])) < 5e-6 and abs(float(d["vm"]) - float(ev["val_mse"])) < 1e-6
+
+
+def _infer_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from anime_recommendations_amd import dist_infer
+        rng = np.random.default_rng(5)
+        W = rng.normal(0, 0.05, (203, 128)).astype(f32)
+        Wh = torch.from_numpy(orc.rownorm(W))
+
+        def cpu_topk(What, q, k, exclude_self=True, keep=None):          # oracle stand-in for the HIP op
+            i, s = orc.cosine_topk(What.numpy(), q.numpy(), k, exclude_self=exclude_self)
+            return torch.from_numpy(i.astype(np.int32)), torch.from_numpy(s)
+
+        idx, sc = dist_infer.sharded_cosine_topk(Wh, 7, topk_fn=cpu_topk)
+        assert idx.shape == (203, 7)
+        lo, hi = dist_infer.shard_bounds(203, rank, world)
+        assert (hi - lo) in (67, 68)
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "infer.npz"), idx=idx.numpy(), sc=sc.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_query_sharded_inference_gathers_the_single_process_result(tmp_path):
+    mp.spawn(_infer_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    d = np.load(tmp_path / "infer.npz")
+    W = np.random.default_rng(5).normal(0, 0.05, (203, 128)).astype(f32)
+    oi, os_ = orc.cosine_topk(orc.rownorm(W), np.arange(203), 7)
+    assert (d["idx"] == oi).all() and (d["sc"] == os_).all()
