@@ -82,6 +82,7 @@ PROTOTYPES = {
     "anirec_train_head": (C.c_int, [_DP, _vp]),
     "anirec_train_bwd": (C.c_int, [_DP, _vp]),
     "anirec_train_adam": (C.c_int, [_DP, _vp]),
+    "anirec_train_adam_part": (C.c_int, [_DP, _i32, _vp]),
     "anirec_trainer_create": (C.c_int, [_DP, C.POINTER(_vp)]),
     "anirec_trainer_destroy": (C.c_int, [_vp]),
     "anirec_trainer_run": (C.c_int, [_vp, _i32, _i32, _vp]),

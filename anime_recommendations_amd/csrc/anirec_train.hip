@@ -686,6 +686,8 @@ __global__ __launch_bounds__(256) void k_densify(DensifyArgs a) {
 struct AdamArgs {
   float *W, *M, *V;
   int n_rows, n_user_rows, n_anime_rows;
+  int row_lo;   // this launch covers rows [row_lo, n_rows)  (n_rows = exclusive upper bound)
+  int parts;    // bit0: write the user-row L2 partials, bit1: the anime-row ones, bit2: finish the step
   int32_t *rowmap;
   const float *P, *S;
   float *anime_grad;  // non-null: anime rows take their gradient from here (already reduced)
@@ -790,7 +792,7 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
   float alpha = 0.f;
   if (kUpdate) alpha = a.pub->alpha;
   float sq = 0.f, sqa = 0.f;  // sum(W_new^2) over user rows / anime rows of this thread
-  int r = blockIdx.x * 8 + (threadIdx.x >> 5);
+  int r = a.row_lo + blockIdx.x * 8 + (threadIdx.x >> 5);
   // two rows in flight per half-wave; the row-map words of the NEXT pair are fetched one
   // iteration ahead so a touched row's chunk partial is requested together with W/M/V
   int rm0 = 0, rm1 = 0;
@@ -831,12 +833,13 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    a.regpart[blockIdx.x] = scratch[0] + scratch[1] + scratch[2] + scratch[3];
-    a.regpart[ANIREC_ADAM_BLOCKS + blockIdx.x] = scratch[4] + scratch[5] + scratch[6] + scratch[7];
+    if (a.parts & 1) a.regpart[blockIdx.x] = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    if (a.parts & 2)
+      a.regpart[ANIREC_ADAM_BLOCKS + blockIdx.x] = scratch[4] + scratch[5] + scratch[6] + scratch[7];
   }
   __syncthreads();
 
-  if (kUpdate && blockIdx.x == 0) {
+  if (kUpdate && blockIdx.x == 0 && (a.parts & 4)) {
     // finish the step: reduce the head partials, Adam on (w, b, gamma, beta), moving stats
     const StepPub pub = *a.pub;
     float h[kHeadCols];
@@ -1086,6 +1089,8 @@ static AdamArgs adam_args(const anirec_train_desc *d, const TrainWs &w) {
   a.M = d->M;
   a.V = d->V;
   a.n_rows = d->n_user_rows + d->n_anime_rows;
+  a.row_lo = 0;
+  a.parts = 7;
   a.n_user_rows = d->n_user_rows;
   a.n_anime_rows = d->n_anime_rows;
   a.rowmap = d->rowmap;
@@ -1100,8 +1105,17 @@ static AdamArgs adam_args(const anirec_train_desc *d, const TrainWs &w) {
   return a;
 }
 
-static int launch_adam(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
+// which: 0 = every row (one launch), 1 = user rows only (may run while the anime gradient is
+// still being all-reduced), 2 = anime rows only + finish the step
+static int launch_adam(const anirec_train_desc *d, const TrainWs &w, hipStream_t s, int which = 0) {
   AdamArgs a = adam_args(d, w);
+  if (which == 1) {
+    a.n_rows = d->n_user_rows;
+    a.parts = 1;
+  } else if (which == 2) {
+    a.row_lo = d->n_user_rows;
+    a.parts = 2 | 4;
+  }
   // tables that overflow the 256-MiB Infinity Cache are streamed non-temporally; small ones
   // (the 7M-rating shape: 50 MB of W+M+V) stay cache-resident between steps
   const size_t table_bytes = (size_t)a.n_rows * kDim * 4 * 3;
@@ -1188,6 +1202,13 @@ int anirec_train_adam(const anirec_train_desc *d, void *stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   return launch_adam(d, carve(d->workspace, d->max_batch, d->arena_steps), (hipStream_t)stream);
+}
+
+int anirec_train_adam_part(const anirec_train_desc *d, int32_t which, void *stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (which != 1 && which != 2) return ANIREC_EINVAL;
+  return launch_adam(d, carve(d->workspace, d->max_batch, d->arena_steps), (hipStream_t)stream, which);
 }
 
 struct anirec_trainer {

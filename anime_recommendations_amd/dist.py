@@ -160,8 +160,12 @@ class DistTrainEngine:
                     self._all_gather_packets()          # (c, t, count) of every rank: BatchNorm sees the global batch
                     e.head()
                     e.bwd()                              # user chunks stay local; anime gradient densified
-                    dist.all_reduce(e.anime_grad)        # RCCL sum over xGMI — the one shared table
-                    e.adam()
+                    # RCCL sum over xGMI of the one shared table, overlapped with the dense Adam
+                    # stream over this rank's user rows (which does not need it)
+                    work = dist.all_reduce(e.anime_grad, async_op=True)
+                    e.adam_users()
+                    work.wait()
+                    e.adam_anime_finish()
                 done += blk
         self.cursor = first_step + n_steps
         return n_steps

@@ -189,6 +189,12 @@ class TrainEngine:
     def adam(self):
         _lib.check(self.lib.anirec_train_adam(C.byref(self.desc), self._sp()), "anirec_train_adam")
 
+    def adam_users(self):
+        _lib.check(self.lib.anirec_train_adam_part(C.byref(self.desc), 1, self._sp()), "anirec_train_adam_part")
+
+    def adam_anime_finish(self):
+        _lib.check(self.lib.anirec_train_adam_part(C.byref(self.desc), 2, self._sp()), "anirec_train_adam_part")
+
     # ---- the hot loop ---------------------------------------------------------------
     def run(self, n_steps=None, use_graph=True, first_step=None):
         """Run n_steps optimiser steps from the current cursor (prep + fwd/head/bwd/adam)."""

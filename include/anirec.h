@@ -154,6 +154,9 @@ int anirec_train_fwd(const anirec_train_desc *d, void *stream);
 int anirec_train_head(const anirec_train_desc *d, void *stream);
 int anirec_train_bwd(const anirec_train_desc *d, void *stream);
 int anirec_train_adam(const anirec_train_desc *d, void *stream);
+/* adam in two launches so the user rows (which == 1) can be updated while the anime gradient is
+ * still in the all-reduce; which == 2 updates the anime rows and finishes the step. */
+int anirec_train_adam_part(const anirec_train_desc *d, int32_t which, void *stream);
 
 /* n_steps full steps (fwd, head, bwd, adam) starting at state->step_fwd.
  * use_graph != 0 replays a captured hipGraph of `graph_steps` steps per launch. */
