@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "anirec_dev.hpp"
@@ -52,15 +53,22 @@ __device__ __forceinline__ float key2f(uint32_t u) {
 }
 
 // fp32 [rows][128] (optionally gathered through `rows`) -> fp16, round to nearest even
+// Key rows excluded by the caller's mask become NaN rows: their scores are NaN, which never compares
+// >= 0 and is ignored by v_max — the filter needs no per-key test (and no load) in the hot loop.
 __global__ __launch_bounds__(256) void k_to_f16(const float *W, const int32_t *rows, int n,
-                                                _Float16 *out) {
+                                                const uint8_t *keep, int zero_nan, _Float16 *out) {
   const int l = threadIdx.x & 31;
   const int nhw = gridDim.x * 8;
   for (int r = blockIdx.x * 8 + (threadIdx.x >> 5); r < n; r += nhw) {
     const int src = rows ? rows[r] : r;
     const float4 x = reinterpret_cast<const float4 *>(W)[(size_t)src * kRowVec + l];
     _Float16 o[4] = {(_Float16)x.x, (_Float16)x.y, (_Float16)x.z, (_Float16)x.w};
-    reinterpret_cast<uint2 *>(out)[(size_t)r * kRowVec + l] = *reinterpret_cast<uint2 *>(o);
+    uint2 v = *reinterpret_cast<uint2 *>(o);
+    if (keep && !keep[r]) v = make_uint2(0x7E007E00u, 0x7E007E00u);
+    // a NaN QUERY row would poison the max over the accumulator registers it shares with other
+    // query rows: it is zeroed here and flagged by k_rerank (its exact scores are NaN anyway)
+    if (zero_nan && (x.x != x.x || x.y != x.y || x.z != x.z || x.w != x.w)) v = make_uint2(0u, 0u);
+    reinterpret_cast<uint2 *>(out)[(size_t)r * kRowVec + l] = v;
   }
 }
 
@@ -68,11 +76,11 @@ struct CandArgs {
   const uint4 *Qb;   // [nq][16] 16-B chunks of fp16 query rows
   const uint4 *Wb;   // [n][16]
   int nq, n, k_eff;
-  const uint8_t *keep;  // optional [n]
   uint2 *cand;          // [nq][kCap] {score bits, key index}
   int32_t *cnt;         // [nq]
   float *theta;         // [nq]
   int32_t *flags;       // [nq] bit0: buffer overflow (dense ties)
+  unsigned long long *dbg;  // kDbg == 2: [0] total appends, [1] compactions
 };
 
 // Wave-cooperative compaction of one row's buffer.  tau = k_eff-th largest MFMA score seen so far is
@@ -137,7 +145,9 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
     for (int i = 0; i < 8; ++i) {
       const int c = tid + 256 * i;  // chunk id: key = c >> 4, chunk = c & 15
       const int key = t * kBN + (c >> 4);
-      stage[i] = key < a.n ? a.Wb[(size_t)key * 16 + (c & 15)] : make_uint4(0, 0, 0, 0);
+      // keys past the end of the table are NaN rows (never candidates)
+      stage[i] = key < a.n ? a.Wb[(size_t)key * 16 + (c & 15)]
+                           : make_uint4(0x7E007E00u, 0x7E007E00u, 0x7E007E00u, 0x7E007E00u);
     }
   };
   auto store_tile = [&](int buf) {
@@ -168,65 +178,62 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
   }
   const uint32_t lt32 = (1u << r32) - 1u;
 
+  // byte offset of each of this lane's 16 rows inside the candidate array (fits 32 bits: nq*kCap*8 < 2^32
+  // is checked on the host)
+  uint32_t rowoff[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g)
+    rowoff[g] = (uint32_t)(q0 + 32 * w + (g & 3) + 8 * (g >> 2) + 4 * h) * (uint32_t)(kCap * 8);
+  char *const cand_bytes = reinterpret_cast<char *>(a.cand);
+
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
     if (t + 1 < ntiles) load_tile(t + 1);  // global loads in flight under the MFMAs
-    // C-in = -theta: the MFMA chain leaves (score - theta); a candidate is simply acc >= 0
-    f32x16 acc[4];
+    // One 32x32 block at a time: 8 chained MFMAs (C-in = -theta, so the chain leaves score - theta and
+    // a candidate is simply acc >= 0), then that block's filter — independent of the next block's
+    // MFMAs, so the two interleave on the SIMD.
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
+    for (int cb = 0; cb < 4; ++cb) {
+      f32x16 acc;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) acc[cb][g] = -thr[g];
+      for (int g = 0; g < 16; ++g) acc[g] = -thr[g];
+      const int krow = cb * 32 + r32;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb) {
-        const int key = cb * 32 + r32;
-        const uint4 bv = Ks[buf][key * 16 + ((2 * ks + h) ^ (key & 15))];
-        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[ks], *reinterpret_cast<const f16x8 *>(&bv),
-                                                         acc[cb], 0, 0, 0);
+      for (int ks = 0; ks < 8; ++ks) {
+        const uint4 bv = Ks[buf][krow * 16 + ((2 * ks + h) ^ (krow & 15))];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[ks], *reinterpret_cast<const f16x8 *>(&bv), acc, 0, 0, 0);
       }
-    }
-    // next tile into the free LDS buffer NOW: the wait on its loads must not also wait for the
-    // candidate stores the epilogue is about to issue (vmcnt retires in order)
-    if (t + 1 < ntiles) store_tile(buf ^ 1);
-    if (kDbg == 1) {
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb) asm volatile("" ::"v"(acc[cb]));
-    }
-    // epilogue: per-register ballots only where a quarter block has a candidate; ranks from
-    // popcounts, one 8-byte store per candidate
-#pragma unroll
-    for (int cb = 0; cb < (kDbg == 1 ? 0 : 4); ++cb) {
+      if (kDbg == 1) {
+        asm volatile("" ::"v"(acc));
+        continue;
+      }
       const int key = t * kBN + cb * 32 + r32;
-      bool ok = key < a.n;
-      if (ok && a.keep) ok = a.keep[key] != 0;
-      // hierarchical reject: one v_max3 + v_max + ballot per 4 accumulator registers (256 scores);
-      // at a pass rate of a few 1e-4 most quarters have no candidate
+      // hierarchical reject: one v_max3 + v_max + ballot per 4 accumulator registers (256 scores)
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
-        const float mq = fmaxf(fmaxf(fmaxf(acc[cb][4 * qd], acc[cb][4 * qd + 1]), acc[cb][4 * qd + 2]),
-                               acc[cb][4 * qd + 3]);
-        if (__ballot(ok && mq >= 0.f)) {
+        // (plain fmaxf: an inline-asm v_max3 reading MFMA results would bypass hipcc's MFMA->VALU
+        // hazard padding and was observed to miss candidates)
+        const float mq = fmaxf(fmaxf(fmaxf(acc[4 * qd], acc[4 * qd + 1]), acc[4 * qd + 2]), acc[4 * qd + 3]);
+        if (__ballot(mq >= 0.f)) {
 #pragma unroll
           for (int gg = 0; gg < 4; ++gg) {
             const int g = 4 * qd + gg;
-            const unsigned long long mk = __ballot(ok && acc[cb][g] >= 0.f);
+            const unsigned long long mk = __ballot(acc[g] >= 0.f);
             if (mk) {  // wave-uniform
               const uint32_t mh = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
-              const bool pass = (mh >> r32) & 1u;
-              const int pos = cntr[g] + __popc(mh & lt32);
-              if (pass && pos < kCap) {
-                const int rl = 32 * w + (g & 3) + 8 * (g >> 2) + 4 * h;
-                a.cand[(size_t)(q0 + rl) * kCap + pos] =
-                    make_uint2(__float_as_uint(acc[cb][g] + thr[g]), (uint32_t)key);
-              }
+              // cnt <= kCap - kBN before the tile and a row gains <= kBN per tile: pos < kCap
+              const uint32_t pos = (uint32_t)cntr[g] + __popc(mh & lt32);
+              if (acc[g] >= 0.f)
+                *reinterpret_cast<uint2 *>(cand_bytes + (rowoff[g] + pos * 8u)) =
+                    make_uint2(__float_as_uint(acc[g] + thr[g]), (uint32_t)key);
               cntr[g] += __popc(mh);
             }
           }
         }
       }
     }
+    // next tile into the free LDS buffer (its readers finished at the previous barrier)
+    if (t + 1 < ntiles) store_tile(buf ^ 1);
     // rows whose buffer could overflow during the next tile: compact now (rare)
     {
       int mx = cntr[0];
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
             int nc;
             float nth;
             compact_row(a.cand + (size_t)(q0 + rl) * kCap, min(c, kCap), a.k_eff, lane, &nc, &nth);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (kDbg == 2 && lane == 0) atomicAdd(&a.dbg[1], 1ull);
             const bool ovf = nc > kCap - kBN;  // more keys inside the window than the buffer can take
             if (lane == 0) {
               cnt_s[rl] = nc;
@@ -324,6 +331,7 @@ __global__ __launch_bounds__(64) void k_rerank(RerankArgs a) {
     u[j] = e < c ? f2key(sc[j]) : 0u;
   }
   bool bad = (a.flags[row] & 1) != 0;
+  if (__ballot(qs[lane] != qs[lane] || qs[lane + 64] != qs[lane + 64])) bad = true;  // NaN query row
   const int kk = min(a.k_eff, a.n);
   if (c < kk) bad = true;
   // tau = kk-th largest bf16 score
@@ -431,6 +439,7 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
   if (n < 1 || nq < 0 || k < 1 || k > ANIREC_MAX_TOPK - 1) return ANIREC_EINVAL;
   if (nq == 0) return ANIREC_OK;
   if (workspace_bytes < anirec_topk_mfma_workspace_bytes(n, nq)) return ANIREC_EWORKSPACE;
+  if ((size_t)nq * kCap * 8 >= ((size_t)1 << 32)) return ANIREC_EINVAL;  // 32-bit candidate offsets: batch the queries
   hipStream_t s = (hipStream_t)stream;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   char *p = (char *)workspace;
@@ -444,12 +453,11 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
   p += al((size_t)nq * 4);
   float *theta = (float *)p;
   p += al((size_t)nq * 4);
-  (void)p;
   int b1 = (n + 7) / 8, b2 = (nq + 7) / 8;
   if (b1 > 8192) b1 = 8192;
   if (b2 > 8192) b2 = 8192;
-  hipLaunchKernelGGL(k_to_f16, dim3(b1), dim3(256), 0, s, What, nullptr, n, Wb);
-  hipLaunchKernelGGL(k_to_f16, dim3(b2), dim3(256), 0, s, What, queries, nq, Qb);
+  hipLaunchKernelGGL(k_to_f16, dim3(b1), dim3(256), 0, s, What, nullptr, n, keep, 0, Wb);
+  hipLaunchKernelGGL(k_to_f16, dim3(b2), dim3(256), 0, s, What, queries, nq, nullptr, 1, Qb);
   ANIREC_HIP_CHECK(hipGetLastError());
   ANIREC_HIP_CHECK(hipMemsetAsync(flags_out, 0, (size_t)nq * 4, s));
   CandArgs ca;
@@ -458,18 +466,27 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
   ca.nq = nq;
   ca.n = n;
   ca.k_eff = exclude_self ? k + 1 : k;
-  ca.keep = keep;
   ca.cand = cand;
   ca.cnt = cnt;
   ca.theta = theta;
   ca.flags = flags_out;
+  ca.dbg = nullptr;
   {
     const char *dbg = getenv("ANIREC_TOPK_DEBUG");
     const int mode = dbg ? atoi(dbg) : 0;
     const dim3 grid((nq + kBM - 1) / kBM);
     if (mode == 1)
       hipLaunchKernelGGL(k_cand<1>, grid, dim3(256), 0, s, ca);
-    else
+    else if (mode == 2) {  // counters land in the first 16 bytes of cnt (debug only)
+      ca.dbg = (unsigned long long *)p;  // the 256 spare bytes at the end of the workspace
+      (void)hipMemsetAsync(p, 0, 16, s);
+      hipLaunchKernelGGL(k_cand<2>, grid, dim3(256), 0, s, ca);
+      unsigned long long hv[2] = {0, 0};
+      (void)hipMemcpyAsync(hv, p, 16, hipMemcpyDeviceToHost, s);
+      (void)hipStreamSynchronize(s);
+      fprintf(stderr, "[anirec topk debug] nq=%d n=%d appends/row=%.1f compactions/row=%.2f\n", nq, n,
+              (double)hv[0] / nq, (double)hv[1] / nq);
+    } else
       hipLaunchKernelGGL(k_cand<0>, grid, dim3(256), 0, s, ca);
   }
   ANIREC_HIP_CHECK(hipGetLastError());
