@@ -44,17 +44,25 @@ RATING_PMF = [0.18, 0.005, 0.005, 0.01, 0.02, 0.05, 0.10, 0.20, 0.22, 0.13, 0.08
 
 def synth_ratings(n_users, n_anime, n, device, seed=20260101):
     """i.i.d. draws from the S7M/S109M marginal laws of SURVEY.md §8(d): users weighted by a
-    lognormal(ln 311, 0.35) activity, anime Zipf(s=1) over a fixed permutation, MAL-like ratings."""
+    lognormal(ln 311, 0.35) activity, anime Zipf(s=1) over a fixed permutation, MAL-like ratings.
+    Inverse-CDF sampling (host fp64 CDFs + seeded device uniforms): bit-reproducible across runs and
+    ranks, unlike torch.multinomial on the GPU."""
     import torch
+    rng = np.random.Generator(np.random.PCG64(seed))
+    act = np.exp(rng.standard_normal(n_users) * 0.35 + np.log(311.0))
+    perm = torch.from_numpy(rng.permutation(n_anime)).to(device)
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    act = torch.exp(torch.randn(n_users, generator=g, device=device) * 0.35 + float(np.log(311.0)))
-    ui = torch.multinomial(act, n, replacement=True, generator=g)
-    ranks = torch.arange(1, n_anime + 1, device=device, dtype=torch.float32)
-    perm = torch.randperm(n_anime, generator=g, device=device)
-    ai = perm[torch.multinomial(1.0 / ranks, n, replacement=True, generator=g)]
-    pmf = torch.tensor(RATING_PMF, device=device)
-    t = torch.multinomial(pmf, n, replacement=True, generator=g).to(torch.float32) / 10.0
+
+    def draw(weights):
+        cdf = np.cumsum(np.asarray(weights, np.float64))
+        cdf = torch.from_numpy(cdf / cdf[-1]).to(device)
+        u = torch.rand(n, generator=g, device=device, dtype=torch.float64)
+        return torch.searchsorted(cdf, u).clamp_(max=len(weights) - 1)
+
+    ui = draw(act)
+    ai = perm[draw(1.0 / np.arange(1, n_anime + 1))]
+    t = draw(RATING_PMF).to(torch.float32) / 10.0
     return ui.to(torch.int32), ai.to(torch.int32), t
 
 

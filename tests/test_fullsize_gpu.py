@@ -1,0 +1,88 @@
+"""Full BASELINE-size checks through size-independent properties (the oracle is too slow at
+these sizes): determinism, exactness of the dense-only Adam update on untouched rows,
+sortedness / self-exclusion / tie order of neighbour lists, agreement of the MFMA paths with the
+exact kernels on samples."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import anirec_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+N_USERS, N_ANIME, B = 350_000, 18_000, 10_000
+
+
+def _train(steps, seed=1):
+    import bench
+    from anime_recommendations_amd.engine import TrainEngine
+    from anime_recommendations_amd import schedule
+    dev = torch.device("cuda:0")
+    ui, ai, t = bench.synth_ratings(N_USERS, N_ANIME, steps * B, dev, seed=seed)
+    U, A = bench.init_tables(N_USERS, N_ANIME, dev)
+    eng = TrainEngine(N_USERS, N_ANIME, max_batch=B, arena_steps=8)
+    eng.set_head(w=1.2)
+    eng.set_weights(U, A)
+    eng.set_epoch(ui, ai, t, np.arange(steps) * B, np.full(steps, B), schedule.adam_alphas(1e-5, 1, steps))
+    eng.run(steps, use_graph=False)
+    eng.synchronize()
+    return eng, U.cpu().numpy(), ui.cpu().numpy()
+
+
+def test_s109m_shape_training_is_deterministic_and_untouched_rows_are_bit_exact():
+    eng1, U0, ui = _train(3)
+    W1, M1, V1 = eng1.W.cpu().numpy(), eng1.M.cpu().numpy(), eng1.V.cpu().numpy()
+    rec1 = eng1.read_state()
+    assert (eng1.rowmap.cpu().numpy() == 0).all() and np.isfinite(rec1["last_loss"])
+    eng1.close()
+    eng2, _, _ = _train(3)
+    assert (eng2.W.cpu().numpy() == W1).all() and (eng2.V.cpu().numpy() == V1).all()
+    assert eng2.read_state()["loss_wsum"] == rec1["loss_wsum"]
+    eng2.close()
+    # rows no batch touched only see g = 2*l2*W: the fused kernel must equal the oracle's Adam bit for bit
+    untouched = np.setdiff1d(np.arange(N_USERS), np.unique(ui))[:5000]
+    w = U0[untouched].copy()
+    m = np.zeros_like(w)
+    v = np.zeros_like(w)
+    for step in range(3):
+        orc.adam_update(w, m, v, np.float32(2e-4) * w, orc.adam_alpha(1e-5, step + 1))
+    assert (W1[untouched] == w).all() and (M1[untouched] == m).all() and (V1[untouched] == v).all()
+
+
+def test_350k_neighbour_lists_properties_and_sample_equals_exact_path():
+    from anime_recommendations_amd import ops
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    W = torch.randn(N_USERS, 128, generator=g, device="cuda") * 0.05
+    W[1000] = W[5]                                     # an exact duplicate pair
+    Wh = ops.rownorm(W)
+    q = torch.arange(0, 4096, dtype=torch.int32, device="cuda")
+    idx, sim, nfb = ops.cosine_topk_mfma(Wh, q, 100)
+    idx, sim = idx.cpu().numpy(), sim.cpu().numpy()
+    assert nfb == 0
+    assert (idx >= 0).all() and (idx != np.arange(4096)[:, None]).all()            # k rows, query dropped
+    assert (np.diff(sim, axis=1) <= 0).all()                                        # descending
+    tie = np.diff(sim, axis=1) == 0
+    assert (np.diff(idx, axis=1)[tie] > 0).all()                                    # ties -> ascending index
+    assert idx[5, 0] == 1000                                                        # the duplicate is the nearest
+    assert all(len(set(r)) == 100 for r in idx[:256])                               # no repeats
+    sample = torch.tensor([0, 5, 17, 999, 4095], dtype=torch.int32, device="cuda")
+    ei, es = ops.cosine_topk(Wh, sample, 100)
+    assert (ei.cpu().numpy() == idx[[0, 5, 17, 999, 4095]]).all()
+    assert (es.cpu().numpy() == sim[[0, 5, 17, 999, 4095]]).all()
+
+
+def test_predict_grid_full_anime_table_matches_pairwise_kernel():
+    from anime_recommendations_amd import ops
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4)
+    U = torch.randn(N_USERS, 128, generator=g, device="cuda") * 0.05
+    A = torch.randn(N_ANIME, 128, generator=g, device="cuda") * 0.05
+    head = dict(w=1.3, b=0.1, gamma=0.9, beta=-0.2, mov_mean=0.05, mov_var=0.4)
+    users = torch.arange(1000, 3048, dtype=torch.int32, device="cuda")
+    G = ops.predict_grid_mfma(U, A, head, users)
+    assert G.shape == (2048, N_ANIME) and bool(((G > 0) & (G < 1)).all())
+    rng = np.random.default_rng(0)
+    ju, ja = rng.integers(0, 2048, 20000), rng.integers(0, N_ANIME, 20000)
+    p = ops.predict_pairs(U, A, head, users[torch.from_numpy(ju).cuda()], ja)
+    np.testing.assert_allclose(G.cpu().numpy()[ju, ja], p.cpu().numpy(), atol=3e-6)
