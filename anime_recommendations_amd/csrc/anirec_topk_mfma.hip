@@ -198,11 +198,13 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[g] = -thr[g];
       const int krow = cb * 32 + r32;
+      // all eight B fragments of the block first (one LDS wait per block instead of one per MFMA pair)
+      uint4 bv[8];
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const uint4 bv = Ks[buf][krow * 16 + ((2 * ks + h) ^ (krow & 15))];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[ks], *reinterpret_cast<const f16x8 *>(&bv), acc, 0, 0, 0);
-      }
+      for (int ks = 0; ks < 8; ++ks) bv[ks] = Ks[buf][krow * 16 + ((2 * ks + h) ^ (krow & 15))];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[ks], *reinterpret_cast<const f16x8 *>(&bv[ks]), acc, 0, 0, 0);
       if (kDbg == 1) {
         asm volatile("" ::"v"(acc));
         continue;
