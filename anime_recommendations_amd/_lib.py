@@ -85,7 +85,7 @@ PROTOTYPES = {
     "anirec_train_adam_part": (C.c_int, [_DP, _i32, _vp]),
     "anirec_trainer_create": (C.c_int, [_DP, C.POINTER(_vp)]),
     "anirec_trainer_destroy": (C.c_int, [_vp]),
-    "anirec_trainer_run": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "anirec_trainer_run": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
     "anirec_eval": (C.c_int, [_DP, _vp, _vp, _vp, _i32, _vp]),
     "anirec_adam_flat": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _f32, _vp]),
     "anirec_gather_ratings": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),

@@ -144,7 +144,9 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum /
 struct PrepArgs {
   const int32_t *user_idx, *anime_idx;
   const anirec_step *sched;
-  int first_step;
+  int first_step;               // absolute first step, or relative to *cursor when cursor != nullptr
+  const anirec_state *cursor;   // device cursor (graph replay): step = cursor->step_fwd + first_step + ...
+  int n_steps_total;            // steps beyond the schedule are skipped
   int n_user_rows, n_anime_rows;
   int cap, capC, arena_steps;
   char *arena;
@@ -158,7 +160,8 @@ __global__ __launch_bounds__(kSortThreads) void k_prep(PrepArgs a) {
   __shared__ uint32_t wsum[kSortWaves];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int step = a.first_step + (blockIdx.x >> 1);
+  const int step = (a.cursor ? a.cursor->step_fwd : 0) + a.first_step + (blockIdx.x >> 1);
+  if (step >= a.n_steps_total) return;  // block-uniform
   const int T = blockIdx.x & 1;  // 0: sort by user row, 1: by anime row
   const anirec_step sc = a.sched[step];
   const int nb = min(sc.count, a.cap);
@@ -572,6 +575,40 @@ struct BwdArgs {
 __global__ __launch_bounds__(256) void k_bwd(BwdArgs a) {
   __shared__ float scratch[2 * 16];
   const StepPub pub = *a.pub;
+  const int l = threadIdx.x & 31;
+  const int hw = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int T = hw >= a.capC ? 1 : 0;
+  const int c = hw - T * a.capC;
+  Slot sl = slot_of(a.arena, a.slot_bytes, a.cap, a.capC, pub.slot);
+  const float4 *W4 = reinterpret_cast<const float4 *>(a.W);
+
+  // Everything this half-wave will need is requested BEFORE the block reduction of the head
+  // partials (a barrier the loads cannot cross): chunk record -> sorted index + other-table row ->
+  // the rating's scalars and the first four rows.  The kernel is a chain of dependent HBM round
+  // trips at this size; this ordering removes one of them.
+  const bool active = c < sl.nchunks[T];
+  int len = 0, i = 0, o = 0;
+  int4 rec = make_int4(0, 0, 0, 0);
+  float ci = 0.f, dyi = 0.f, su = 1.f, sa = 1.f;
+  float4 r0[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) r0[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active) {
+    rec = sl.chunks[T * a.capC + c];
+    len = rec.z;
+    // lane j < len holds contribution j of the chunk; the rest replicate the last one with
+    // weight 0 so every shuffle source is a valid row
+    const int pos = rec.y + min(l, len - 1);
+    i = sl.sidx[T * a.cap + pos];
+    o = sl.oth[T * a.cap + pos];
+    ci = a.pk_c[i];
+    dyi = a.dy[i];
+    su = a.su[i];
+    sa = a.sa[i];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r0[q] = W4[(size_t)__shfl(o, q, 32) * kRowVec + l];
+  }
+
   // mean(d zhat), mean(d zhat * zhat) from the head partials (fixed order)
   float m[2] = {0.f, 0.f};
   for (int k = threadIdx.x; k < pub.n_head_blocks; k += 256) {
@@ -579,28 +616,14 @@ __global__ __launch_bounds__(256) void k_bwd(BwdArgs a) {
     m[1] += a.hpart[(size_t)k * kHeadCols + 1];
   }
   block_sum<2>(m, scratch);
+  if (!active) return;
   const float Bf = (float)pub.n_total;
   const float m1 = pub.gamma * m[0] / Bf;
   const float m2 = pub.gamma * m[1] / Bf;
 
-  const int hw = blockIdx.x * 8 + (threadIdx.x >> 5);
-  const int T = hw >= a.capC ? 1 : 0;
-  const int c = hw - T * a.capC;
-  Slot sl = slot_of(a.arena, a.slot_bytes, a.cap, a.capC, pub.slot);
-  if (c >= sl.nchunks[T]) return;
-  const int l = threadIdx.x & 31;
-  const int4 rec = sl.chunks[T * a.capC + c];
-  const int len = rec.z;
-  // lane j < len holds contribution j of the chunk; the rest replicate the last one with
-  // weight 0 so every shuffle source is a valid row
-  const int pos = rec.y + min(l, len - 1);
-  const int i = sl.sidx[T * a.cap + pos];
-  const int o = sl.oth[T * a.cap + pos];
   float cf, sf;
   {
     // closed-form backward of BatchNorm + Dense(1) + normalised dot for rating i
-    const float ci = a.pk_c[i], dyi = a.dy[i];
-    const float su = a.su[i], sa = a.sa[i];
     const float z = ci * pub.w + pub.b;
     const float zh = (z - pub.mu) * pub.rs;
     const float dz = (dyi * pub.gamma - m1 - zh * m2) * pub.rs;
@@ -616,9 +639,16 @@ __global__ __launch_bounds__(256) void k_bwd(BwdArgs a) {
     cf = 0.f;
     sf = 0.f;
   }
-  const float4 *W4 = reinterpret_cast<const float4 *>(a.W);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int j = 0; j < len; j += 4) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {  // contributions 0..3 (rows already here; weight 0 past len)
+    const float cq = __shfl(cf, q, 32);
+    acc.x += cq * r0[q].x;
+    acc.y += cq * r0[q].y;
+    acc.z += cq * r0[q].z;
+    acc.w += cq * r0[q].w;
+  }
+  for (int j = 4; j < len; j += 4) {
     int oj[4];
     float cj[4];
     float4 r[4];
@@ -1152,6 +1182,26 @@ int anirec_train_init_reg(const anirec_train_desc *d, void *stream) {
   return (int)hipGetLastError();
 }
 
+static int launch_prep(const anirec_train_desc *d, const TrainWs &w, int first_step, int n_steps,
+                       bool relative_to_cursor, hipStream_t s) {
+  PrepArgs a;
+  a.user_idx = d->user_idx;
+  a.anime_idx = d->anime_idx;
+  a.sched = d->sched;
+  a.first_step = first_step;
+  a.cursor = relative_to_cursor ? d->state : nullptr;
+  a.n_steps_total = d->n_steps;
+  a.n_user_rows = d->n_user_rows;
+  a.n_anime_rows = d->n_anime_rows;
+  a.cap = w.cap;
+  a.capC = w.capC;
+  a.arena_steps = w.arena_steps;
+  a.arena = w.arena;
+  a.slot_bytes = w.slot_bytes;
+  hipLaunchKernelGGL(k_prep, dim3(2 * n_steps), dim3(kSortThreads), 0, s, a);
+  return (int)hipGetLastError();
+}
+
 int anirec_train_prep(const anirec_train_desc *d, int32_t first_step, int32_t n_steps,
                       void *stream) {
   int rc = check_desc(d);
@@ -1161,21 +1211,8 @@ int anirec_train_prep(const anirec_train_desc *d, int32_t first_step, int32_t n_
       n_steps > d->arena_steps)
     return ANIREC_EINVAL;
   if (n_steps == 0) return ANIREC_OK;
-  TrainWs w = carve(d->workspace, d->max_batch, d->arena_steps);
-  PrepArgs a;
-  a.user_idx = d->user_idx;
-  a.anime_idx = d->anime_idx;
-  a.sched = d->sched;
-  a.first_step = first_step;
-  a.n_user_rows = d->n_user_rows;
-  a.n_anime_rows = d->n_anime_rows;
-  a.cap = w.cap;
-  a.capC = w.capC;
-  a.arena_steps = w.arena_steps;
-  a.arena = w.arena;
-  a.slot_bytes = w.slot_bytes;
-  hipLaunchKernelGGL(k_prep, dim3(2 * n_steps), dim3(kSortThreads), 0, (hipStream_t)stream, a);
-  return (int)hipGetLastError();
+  return launch_prep(d, carve(d->workspace, d->max_batch, d->arena_steps), first_step, n_steps, false,
+                     (hipStream_t)stream);
 }
 
 int anirec_train_fwd(const anirec_train_desc *d, void *stream) {
@@ -1248,18 +1285,28 @@ static int one_step(anirec_trainer *t, hipStream_t s) {
   return launch_adam(&t->d, t->ws, s);
 }
 
-int anirec_trainer_run(anirec_trainer *t, int32_t n_steps, int32_t use_graph, void *stream) {
-  if (!t || n_steps < 0) return ANIREC_EINVAL;
+// Runs steps [first_step, first_step + n_steps); first_step must equal the device cursor
+// (state->step_fwd).  The batch prep (sort + chunk tables) is driven from here: with use_graph a
+// captured graph of G steps starts with the prep of the G steps AFTER it (relative to the device
+// cursor), so a replay needs no host work between blocks; the arena holds 2G steps.
+int anirec_trainer_run(anirec_trainer *t, int32_t first_step, int32_t n_steps, int32_t use_graph,
+                       void *stream) {
+  if (!t || n_steps < 0 || first_step < 0 || first_step + n_steps > t->d.n_steps) return ANIREC_EINVAL;
+  if (!t->d.user_idx || !t->d.anime_idx || !t->d.rating || !t->d.sched) return ANIREC_EINVAL;
+  if (n_steps == 0) return ANIREC_OK;
   hipStream_t s = (hipStream_t)stream;
-  constexpr int kGraphSteps = 16;
+  int G = t->d.arena_steps / 2;
+  if (G > 32) G = 32;
   int done = 0;
-  if (use_graph && s != nullptr && n_steps >= kGraphSteps) {
-    if (!t->exec) {
+  if (use_graph && s != nullptr && G >= 4 && n_steps >= G) {
+    if (!t->exec || t->graph_steps != G) {
+      if (t->exec) (void)hipGraphExecDestroy(t->exec);
+      t->exec = nullptr;
       hipGraph_t g = nullptr;
       if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess)
         return ANIREC_ECAPTURE;
-      int e = 0;
-      for (int i = 0; i < kGraphSteps && !e; ++i) e = one_step(t, s);
+      int e = launch_prep(&t->d, t->ws, G, G, true, s);  // steps cursor+G .. cursor+2G
+      for (int i = 0; i < G && !e; ++i) e = one_step(t, s);
       hipError_t ce = hipStreamEndCapture(s, &g);
       if (e || ce != hipSuccess || !g) {
         if (g) (void)hipGraphDestroy(g);
@@ -1271,16 +1318,30 @@ int anirec_trainer_run(anirec_trainer *t, int32_t n_steps, int32_t use_graph, vo
         t->exec = nullptr;
         return ANIREC_ECAPTURE;
       }
-      t->graph_steps = kGraphSteps;
+      t->graph_steps = G;
     }
-    while (n_steps - done >= t->graph_steps) {
-      ANIREC_HIP_CHECK(hipGraphLaunch(t->exec, s));
-      done += t->graph_steps;
-    }
-  }
-  for (; done < n_steps; ++done) {
-    int e = one_step(t, s);
+    int e = launch_prep(&t->d, t->ws, first_step, G, false, s);  // the first block; later ones by the graph
     if (e) return e;
+    while (n_steps - done >= G) {
+      ANIREC_HIP_CHECK(hipGraphLaunch(t->exec, s));
+      done += G;
+    }
+    // the last replay already prepared steps [first_step+done, first_step+done+G): the tail is covered
+  } else {
+    // no graph: prepare arena-sized blocks from the host
+  }
+  while (done < n_steps) {
+    int blk = n_steps - done;
+    if (!(use_graph && s != nullptr && G >= 4 && done > 0)) {  // tail after a replay is prepared already
+      if (blk > t->d.arena_steps) blk = t->d.arena_steps;
+      int e = launch_prep(&t->d, t->ws, first_step + done, blk, false, s);
+      if (e) return e;
+    }
+    for (int i = 0; i < blk; ++i) {
+      int e = one_step(t, s);
+      if (e) return e;
+    }
+    done += blk;
   }
   return ANIREC_OK;
 }

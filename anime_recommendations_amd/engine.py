@@ -208,14 +208,8 @@ class TrainEngine:
             h = C.c_void_p()
             _lib.check(self.lib.anirec_trainer_create(C.byref(self.desc), C.byref(h)), "anirec_trainer_create")
             self._trainer = h
-        done = 0
-        while done < n_steps:
-            blk = min(self.arena_steps, n_steps - done)
-            # keep (step % arena_steps) slots distinct inside one block
-            self.prep(first_step + done, blk)
-            _lib.check(self.lib.anirec_trainer_run(self._trainer, blk, int(use_graph), self._sp()),
-                       "anirec_trainer_run")
-            done += blk
+        _lib.check(self.lib.anirec_trainer_run(self._trainer, int(first_step), int(n_steps), int(use_graph),
+                                               self._sp()), "anirec_trainer_run")
         return n_steps
 
     def eval_sums(self, user_idx, anime_idx, rating):

@@ -158,12 +158,15 @@ int anirec_train_adam(const anirec_train_desc *d, void *stream);
  * still in the all-reduce; which == 2 updates the anime rows and finishes the step. */
 int anirec_train_adam_part(const anirec_train_desc *d, int32_t which, void *stream);
 
-/* n_steps full steps (fwd, head, bwd, adam) starting at state->step_fwd.
- * use_graph != 0 replays a captured hipGraph of `graph_steps` steps per launch. */
+/* Steps [first_step, first_step + n_steps) — prep, fwd, head, bwd, adam — on one GPU; first_step
+ * must equal the device cursor state->step_fwd.  use_graph != 0 replays a captured hipGraph of
+ * G = min(32, arena_steps/2) steps whose first node prepares the G steps after it, so no host
+ * work is needed between replays. */
 typedef struct anirec_trainer anirec_trainer; /* host-side handle: descriptor copy + graph cache */
 int anirec_trainer_create(const anirec_train_desc *d, anirec_trainer **out_host);
 int anirec_trainer_destroy(anirec_trainer *t);
-int anirec_trainer_run(anirec_trainer *t, int32_t n_steps, int32_t use_graph, void *stream);
+int anirec_trainer_run(anirec_trainer *t, int32_t first_step, int32_t n_steps, int32_t use_graph,
+                       void *stream);
 
 /* Validation pass on n rows (BN inference, moving stats): accumulates
  * state->val_* ; val_loss = val_bce_sum/val_n + l2*reg_sumsq  (neural_network.py:216). */

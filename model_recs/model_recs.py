@@ -55,4 +55,9 @@ def go(args):
 
 
 if __name__ == "__main__":
-    go(C.make_parser("Get anime recommendations from the ranking model", STR_FLAGS, BOOL_FLAGS).parse_args())
+    _args = C.make_parser("Get anime recommendations from the ranking model", STR_FLAGS, BOOL_FLAGS).parse_args()
+    try:
+        go(_args)
+    except Exception:                      # non-zero exit + the reason in ./model_recs.log
+        logger.exception("model_recs failed")
+        raise

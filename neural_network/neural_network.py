@@ -103,4 +103,9 @@ def go(args):
 
 
 if __name__ == "__main__":
-    go(C.make_parser("Train an anime recommendation neural network", STR_FLAGS, BOOL_FLAGS).parse_args())
+    _args = C.make_parser("Train an anime recommendation neural network", STR_FLAGS, BOOL_FLAGS).parse_args()
+    try:
+        go(_args)
+    except Exception:                      # non-zero exit + the reason in ./neural_network.log
+        logger.exception("neural_network failed")
+        raise

@@ -49,4 +49,9 @@ def go(args):
 
 
 if __name__ == "__main__":
-    go(C.make_parser("Get recommendations based on similar anime", STR_FLAGS, BOOL_FLAGS).parse_args())
+    _args = C.make_parser("Get recommendations based on similar anime", STR_FLAGS, BOOL_FLAGS).parse_args()
+    try:
+        go(_args)
+    except Exception:                      # non-zero exit + the reason in ./similar_anime.log
+        logger.exception("similar_anime failed")
+        raise

@@ -50,4 +50,9 @@ def go(args):
 
 
 if __name__ == "__main__":
-    go(C.make_parser("Find the users most similar to a user", STR_FLAGS, BOOL_FLAGS).parse_args())
+    _args = C.make_parser("Find the users most similar to a user", STR_FLAGS, BOOL_FLAGS).parse_args()
+    try:
+        go(_args)
+    except Exception:                      # non-zero exit + the reason in ./similar_users.log
+        logger.exception("similar_users failed")
+        raise
