@@ -376,6 +376,29 @@ __global__ __launch_bounds__(256) void k_fwd(FwdArgs a) {
   }
 }
 
+// Multi-GPU only: (mean, M2) of this rank's z = w*c + b values, two-pass, written next to the
+// count in the packet tail so that the all-gathered packets carry every rank's statistics.
+__global__ __launch_bounds__(1024) void k_seg_stats(float *pk, int pcap, int cap,
+                                                    const anirec_state *st) {
+  __shared__ float scratch[16];
+  const int cnt = min(reinterpret_cast<const int32_t *>(pk + 2 * (size_t)pcap)[0], cap);
+  const float w = st->w, b = st->b;
+  float r[1] = {0.f};
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) r[0] += pk[i] * w + b;
+  block_sum<1>(r, scratch);
+  const float mean = cnt > 0 ? r[0] / (float)cnt : 0.f;
+  r[0] = 0.f;
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+    const float d = (pk[i] * w + b) - mean;
+    r[0] += d * d;
+  }
+  block_sum<1>(r, scratch);
+  if (threadIdx.x == 0) {
+    pk[2 * (size_t)pcap + 1] = mean;
+    pk[2 * (size_t)pcap + 2] = r[0];
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // head: Dense(1) -> BatchNorm(batch stats) -> sigmoid -> BCE, spread over many workgroups.
 // Every workgroup recomputes the batch mean/variance of z from all c (two-pass, no
@@ -475,26 +498,41 @@ __global__ __launch_bounds__(kHeadThreads) void k_head(HeadArgs a) {
   }
   const float Bf = (float)n_total;
 
-  // ---- batch statistics of z over the whole (global) batch, redundantly per workgroup ----
+  // ---- batch statistics of z over the whole (global) batch ------------------------------------
   float mu, var;
-  {
+  if (a.n_seg == 1) {
+    // one rank: two passes over the 40 KB of c (registers), redundantly per workgroup
     float r[1];
     r[0] = seg_stat<false>(x0, cnts[0], w, b, 0.f);
-    for (int s = 1; s < a.n_seg; ++s) {
-      SegVals xs;
-      seg_load(a.packets + a.packet_floats * s, pcap, xs);
-      r[0] += seg_stat<false>(xs, packet_count(a.packets + a.packet_floats * s, a.cap), w, b, 0.f);
-    }
     block_sum<1>(r, scratch);
     mu = r[0] / Bf;
     r[0] = seg_stat<true>(x0, cnts[0], w, b, mu);
-    for (int s = 1; s < a.n_seg; ++s) {
-      SegVals xs;
-      seg_load(a.packets + a.packet_floats * s, pcap, xs);
-      r[0] += seg_stat<true>(xs, packet_count(a.packets + a.packet_floats * s, a.cap), w, b, mu);
-    }
     block_sum<1>(r, scratch);
     var = r[0] / Bf;  // biased (tf.nn.moments)
+  } else {
+    // several ranks: every packet carries (count, mean, M2) of its own z values (k_seg_stats on
+    // the owning rank, same w and b everywhere); merge them in rank order (Chan et al.)
+    double nsum = 0.0, msum = 0.0;
+#pragma unroll
+    for (int s = 0; s < ANIREC_MAX_SEG; ++s) {
+      if (s < a.n_seg && cnts[s] > 0) {
+        const float *tail = a.packets + a.packet_floats * s + 2 * (size_t)pcap;
+        nsum += (double)cnts[s];
+        msum += (double)cnts[s] * (double)tail[1];
+      }
+    }
+    const double mean = msum / nsum;
+    double m2 = 0.0;
+#pragma unroll
+    for (int s = 0; s < ANIREC_MAX_SEG; ++s) {
+      if (s < a.n_seg && cnts[s] > 0) {
+        const float *tail = a.packets + a.packet_floats * s + 2 * (size_t)pcap;
+        const double dm = (double)tail[1] - mean;
+        m2 += (double)tail[2] + (double)cnts[s] * dm * dm;
+      }
+    }
+    mu = (float)mean;
+    var = (float)(m2 / nsum);
   }
   const float rs = 1.0f / sqrtf(var + kBnEps);
   const float inv = rs * gamma;
@@ -1055,6 +1093,9 @@ static int launch_fwd(const anirec_train_desc *d, const TrainWs &w, hipStream_t 
   a.sa = w.sa;
   a.cap = d->max_batch;
   hipLaunchKernelGGL(k_fwd, dim3((d->max_batch + 7) / 8), dim3(256), 0, s, a);
+  if (d->n_seg > 1)
+    hipLaunchKernelGGL(k_seg_stats, dim3(1), dim3(1024), 0, s, pk, packet_cap(d->max_batch), d->max_batch,
+                       d->state);
   return (int)hipGetLastError();
 }
 

@@ -81,6 +81,9 @@ class NumpyStageEngine:
         pk[:n] = self.c
         pk[self.pcap:self.pcap + n] = lt
         pk[2 * self.pcap:2 * self.pcap + 1].view(np.int32)[0] = n
+        z = self.c * self.hd["w"] + self.hd["b"]                     # k_seg_stats: (mean, M2) of this rank's z
+        pk[2 * self.pcap + 1] = np.mean(z, dtype=f32) if n else 0
+        pk[2 * self.pcap + 2] = np.sum((z - pk[2 * self.pcap + 1]) ** 2, dtype=f32)
 
     def head_stage(self):
         cs, ts = [], []
