@@ -230,6 +230,35 @@ def run_cosine_topk(cpu_baseline=True):
     return out
 
 
+def run_gather_roofline():
+    """The embedding-forward kernel body (two 512-B row gathers + three dot-128 reductions per rating,
+    k_predict_pairs == k_fwd without the batch bookkeeping) on 4 M random pairs: the HBM gather rate
+    the kernel reaches when a launch is not 10 000 ratings (10 MB, latency-bound) long."""
+    import torch
+    from anime_recommendations_amd import ops
+    n_u, n_a, n = 350_000, 18_000, 4_000_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    U = torch.randn(n_u, 128, generator=g, device="cuda") * 0.05
+    A = torch.randn(n_a, 128, generator=g, device="cuda") * 0.05
+    ui = torch.randint(0, n_u, (n,), generator=g, device="cuda", dtype=torch.int32)
+    ai = torch.randint(0, n_a, (n,), generator=g, device="cuda", dtype=torch.int32)
+    head = dict(w=1.3, b=0.1, gamma=0.9, beta=-0.2, mov_mean=0.05, mov_var=0.4)
+    ops.predict_pairs(U, A, head, ui, ai)
+    torch.cuda.synchronize()
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ops.predict_pairs(U, A, head, ui, ai)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    gbs = n * 1036 / dt / 1e9
+    return {"value": n / dt, "unit": "pairs/s", "ms": dt * 1e3,
+            "roofline": {"kernel": "k_predict_pairs (embedding forward body), 4 M pairs", "bound": "hbm",
+                         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": None}}
+
+
 def run_predict_grid(cpu_baseline=True):
     """BASELINE.json configs[4]: predicted ratings of all 18 000 anime for 100 000 query users
     (the full fp32 grid is written: 7.2 GB, HBM-write-bound)."""
@@ -314,6 +343,7 @@ def main():
     if not args.no_also:
         line["also"]["cosine_topk"] = run_cosine_topk(cpu_baseline=not args.no_cpu_baseline)
         line["also"]["predict_grid_100k_x_18k"] = run_predict_grid(cpu_baseline=not args.no_cpu_baseline)
+        line["also"]["embed_fwd_gather_4M_pairs"] = run_gather_roofline()
     print(json.dumps(line))
 
 
