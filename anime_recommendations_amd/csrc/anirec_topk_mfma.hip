@@ -4,17 +4,22 @@
 // similar_users.py:293-296) at BASELINE scale (every row a query, top-100 of 18 k / 350 k rows) without
 // ever materialising the n x n score matrix.
 //
-// Two kernels:
-//   k_cand    v_mfma_f32_32x32x16_f16 scores of 128 queries x all keys per workgroup (fp16 operands:
-//             the bf16 MFMA rate with 8x smaller rounding error); each query row keeps a candidate
-//             buffer in HBM/L2 and a running threshold + count in registers; a row's buffer is
-//             compacted (exact radix select of the M-th largest score) when it fills.  Because
-//             thresholds only rise, the buffer finally holds EVERY key whose MFMA score is >= theta.
+// Three kernels:
+//   k_cand    one SUPER-STEP of the key stream: v_mfma_f32_32x32x16_f16 scores of 128 queries x a range
+//             of key tiles per workgroup (fp16 operands: the bf16 MFMA rate with 8x smaller rounding
+//             error).  Each query row has a candidate buffer in HBM/L2 and, in registers, a count and a
+//             threshold theta that is FIXED for the launch and folded into the MFMA accumulator
+//             (C-in = -theta): a candidate is `acc >= 0`; ranks come from wave ballots (no atomics).
+//   k_refresh between super-steps, one wave per row: tau = k-th largest MFMA score seen so far is a
+//             lower bound of the final one, so theta = tau - 2 eps keeps every key that can still reach
+//             the exact top-k; the buffer is compacted.  Super-steps double the keys seen, so a row
+//             gains ~k candidates per super-step and no MFMA workgroup ever waits for a compaction.
 //   k_rerank  per query: tau = k-th largest MFMA score; MFMA scores of unit vectors are within
 //             eps = 2^-10 (+ fp32 accumulation) of the exact score, so the exact top-k is contained in
-//             {MFMA score >= tau - 2 eps}; if theta <= tau - 2 eps that set is complete -> its members
+//             {MFMA score >= tau - 2 eps} — complete because theta <= tau - 2 eps.  Its members
 //             are re-scored with the DEFINED fp32 fma chain and ranked (ties: ascending index).
-//             Otherwise the row is flagged and the caller re-runs it through the exact kernels.
+//             Rows whose window overflowed (dense near-duplicates) are flagged and the caller re-runs
+//             them through the exact kernels.
 // Result: bit-exact neighbour lists at matrix-core speed.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -28,7 +33,7 @@ namespace anirec {
 
 constexpr int kBM = 128;        // query rows per workgroup (4 waves x 32 rows)
 constexpr int kBN = 128;        // keys per tile
-constexpr int kCap = 512;       // candidate buffer entries per query row (compacted when > kCap - kBN)
+constexpr int kCap = 512;       // candidate buffer entries per query row
 // |fp16-operand MFMA score - fp32 fma-chain score| for unit-norm rows: each operand is rounded with
 // unit roundoff 2^-11 (fp16 has 11 significant bits: 8x tighter than bf16's 2^-8, at the same MFMA
 // rate), so a product is off by <= 2^-10 (1 + 2^-12) of |q_k w_k| and sum |q_k w_k| <= 1; fp16
@@ -76,18 +81,27 @@ struct CandArgs {
   const uint4 *Qb;   // [nq][16] 16-B chunks of fp16 query rows
   const uint4 *Wb;   // [n][16]
   int nq, n, k_eff;
-  uint2 *cand;          // [nq][kCap] {score bits, key index}
-  int32_t *cnt;         // [nq]
-  float *theta;         // [nq]
-  int32_t *flags;       // [nq] bit0: buffer overflow (dense ties)
-  unsigned long long *dbg;  // kDbg == 2: [0] total appends, [1] compactions
+  int tile0, tile1;  // this launch scans key tiles [tile0, tile1)
+  uint2 *cand;       // [nq][kCap] {score bits, key index}
+  int32_t *cnt;      // [nq]
+  float *theta;      // [nq]
+  int32_t *flags;    // [nq] bit0: buffer overflow (dense ties)
+  unsigned long long *dbg;  // kDbg == 2: [0] total appends
 };
 
-// Wave-cooperative compaction of one row's buffer.  tau = k_eff-th largest MFMA score seen so far is
-// a lower bound of the final one, so only keys with score >= tau - 2 eps can still matter: the new
-// threshold.  (one copy in the binary: called from a rare, non-unrolled loop)
-__device__ __noinline__ void compact_row(uint2 *cand_row, int c, int k_eff, int lane, int *out_cnt,
-                                         float *out_theta) {
+// ------------------------------------------------------------------------------------
+// k_refresh: one wave per query row, between two super-steps of the key stream.
+// tau = k_eff-th largest MFMA score seen so far is a lower bound of the final one, so only keys with
+// score >= tau - 2 eps can still matter: that becomes the row's threshold for the next super-step and
+// everything below it is dropped from the buffer.  Fully parallel over the rows (no workgroup of the
+// MFMA kernel ever waits for a compaction).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_refresh(CandArgs a) {
+  const int lane = threadIdx.x;
+  const int row = blockIdx.x;
+  uint2 *cand_row = a.cand + (size_t)row * kCap;
+  const int c = min(a.cnt[row], kCap);
+  if (c < a.k_eff) return;  // not enough candidates yet (tiny tables): keep the threshold
   uint2 en[kCap / 64];
   uint32_t u[kCap / 64];
 #pragma unroll
@@ -102,7 +116,7 @@ __device__ __noinline__ void compact_row(uint2 *cand_row, int c, int k_eff, int 
     int cge = 0;  // wave-uniform: ballots + scalar popcounts, no cross-lane shuffles
 #pragma unroll
     for (int j = 0; j < kCap / 64; ++j) cge += __popcll(__ballot(u[j] >= trial));
-    if (cge >= k_eff) prefix = trial;
+    if (cge >= a.k_eff) prefix = trial;
   }
   const float th = key2f(prefix) - 2.f * kEpsMfma;
   int nc = 0;
@@ -114,15 +128,19 @@ __device__ __noinline__ void compact_row(uint2 *cand_row, int c, int k_eff, int 
     if (kp) cand_row[nc + __popcll(m & lt)] = en[j];  // nc + rank < c <= kCap
     nc += __popcll(m);
   }
-  *out_cnt = nc;
-  *out_theta = th;
+  if (lane == 0) {
+    a.cnt[row] = nc;
+    a.theta[row] = th;
+  }
 }
 
-template <int kDbg>  // 0: product; 1: no epilogue (timing experiments only)
+// ------------------------------------------------------------------------------------
+// k_cand: one super-step.  128 query rows per workgroup (4 waves x 32 rows, fragments in registers),
+// key tiles of 128 rows double-buffered in XOR-swizzled LDS, thresholds FIXED for the launch.
+// ------------------------------------------------------------------------------------
+template <int kDbg>  // 0: product; 1: no epilogue (timing experiments only); 2: count appends
 __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
-  __shared__ __attribute__((aligned(16))) uint4 Ks[2][kBN * 16];  // 2 x 32 KB, XOR-swizzled chunks
-  __shared__ int cnt_s[kBM];
-  __shared__ float theta_s[kBM];
+  __shared__ __attribute__((aligned(16))) uint4 Ks[2][kBN * 16];  // 2 x 32 KB
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r32 = lane & 31, h = lane >> 5;
   const int q0 = blockIdx.x * kBM;
@@ -138,7 +156,6 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
       qa[ks] = *reinterpret_cast<f16x8 *>(&v);
     }
   }
-  const int ntiles = (a.n + kBN - 1) / kBN;
   uint4 stage[8];
   auto load_tile = [&](int t) {
 #pragma unroll
@@ -158,47 +175,38 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
       Ks[buf][key * 16 + (ch ^ (key & 15))] = stage[i];
     }
   };
-  load_tile(0);
+  load_tile(a.tile0);
   store_tile(0);
-  if (tid < kBM) {
-    cnt_s[tid] = 0;
-    theta_s[tid] = (q0 + tid < a.nq) ? kThetaInit : INFINITY;
-  }
-  __syncthreads();
 
-  // Accumulator register g of a 32x32 block belongs to query row (g&3) + 8(g>>2) + 4h of the
-  // wave's 32 rows: the rows are private to the wave, so their thresholds and buffer counts live
-  // in registers (replicated over the 32 lanes of a half-wave) — no LDS, no atomics in the loop.
+  // Accumulator register g of a 32x32 block belongs to query row (g&3) + 8(g>>2) + 4h of the wave's
+  // 32 rows: the rows are private to the wave, so their thresholds and buffer counts live in
+  // registers (replicated over the 32 lanes of a half-wave) — no LDS, no atomics in the loop.
   float thr[16];
   int cntr[16];
+  uint32_t rowoff[16];  // byte offset of the row's buffer (nq*kCap*8 < 2^32 is checked on the host)
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
-    thr[g] = theta_s[32 * w + (g & 3) + 8 * (g >> 2) + 4 * h];
-    cntr[g] = 0;
+    const int rl = q0 + 32 * w + (g & 3) + 8 * (g >> 2) + 4 * h;
+    const bool live = rl < a.nq;
+    thr[g] = live ? a.theta[rl] : INFINITY;
+    cntr[g] = live ? a.cnt[rl] : 0;
+    rowoff[g] = (uint32_t)rl * (uint32_t)(kCap * 8);
   }
   const uint32_t lt32 = (1u << r32) - 1u;
-
-  // byte offset of each of this lane's 16 rows inside the candidate array (fits 32 bits: nq*kCap*8 < 2^32
-  // is checked on the host)
-  uint32_t rowoff[16];
-#pragma unroll
-  for (int g = 0; g < 16; ++g)
-    rowoff[g] = (uint32_t)(q0 + 32 * w + (g & 3) + 8 * (g >> 2) + 4 * h) * (uint32_t)(kCap * 8);
   char *const cand_bytes = reinterpret_cast<char *>(a.cand);
+  __syncthreads();
 
-  for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < ntiles) load_tile(t + 1);  // global loads in flight under the MFMAs
+  for (int t = a.tile0; t < a.tile1; ++t) {
+    const int buf = (t - a.tile0) & 1;
+    if (t + 1 < a.tile1) load_tile(t + 1);  // global loads in flight under the MFMAs
     // One 32x32 block at a time: 8 chained MFMAs (C-in = -theta, so the chain leaves score - theta and
-    // a candidate is simply acc >= 0), then that block's filter — independent of the next block's
-    // MFMAs, so the two interleave on the SIMD.
+    // a candidate is simply acc >= 0), then that block's filter.
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
       f32x16 acc;
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[g] = -thr[g];
       const int krow = cb * 32 + r32;
-      // all eight B fragments of the block first (one LDS wait per block instead of one per MFMA pair)
       uint4 bv[8];
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) bv[ks] = Ks[buf][krow * 16 + ((2 * ks + h) ^ (krow & 15))];
@@ -210,11 +218,11 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
         continue;
       }
       const int key = t * kBN + cb * 32 + r32;
-      // hierarchical reject: one v_max3 + v_max + ballot per 4 accumulator registers (256 scores)
+      // hierarchical reject: one max over 4 accumulator registers (256 scores) + a ballot
+      // (plain fmaxf: an inline-asm v_max3 reading MFMA results would bypass hipcc's MFMA->VALU
+      // hazard padding and was observed to miss candidates)
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
-        // (plain fmaxf: an inline-asm v_max3 reading MFMA results would bypass hipcc's MFMA->VALU
-        // hazard padding and was observed to miss candidates)
         const float mq = fmaxf(fmaxf(fmaxf(acc[4 * qd], acc[4 * qd + 1]), acc[4 * qd + 2]), acc[4 * qd + 3]);
         if (__ballot(mq >= 0.f)) {
 #pragma unroll
@@ -223,66 +231,39 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
             const unsigned long long mk = __ballot(acc[g] >= 0.f);
             if (mk) {  // wave-uniform
               const uint32_t mh = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
-              // cnt <= kCap - kBN before the tile and a row gains <= kBN per tile: pos < kCap
               const uint32_t pos = (uint32_t)cntr[g] + __popc(mh & lt32);
-              if (acc[g] >= 0.f)
+              if (acc[g] >= 0.f && pos < (uint32_t)kCap)
                 *reinterpret_cast<uint2 *>(cand_bytes + (rowoff[g] + pos * 8u)) =
                     make_uint2(__float_as_uint(acc[g] + thr[g]), (uint32_t)key);
               cntr[g] += __popc(mh);
+              if (kDbg == 2 && lane == 0) atomicAdd(&a.dbg[0], (unsigned long long)__popcll(mk));
             }
           }
         }
       }
     }
     // next tile into the free LDS buffer (its readers finished at the previous barrier)
-    if (t + 1 < ntiles) store_tile(buf ^ 1);
-    // rows whose buffer could overflow during the next tile: compact now (rare)
-    {
-      int mx = cntr[0];
-#pragma unroll
-      for (int g = 1; g < 16; ++g) mx = max(mx, cntr[g]);
-      if (__ballot(mx > kCap - kBN)) {
-        if (r32 == 0) {
-#pragma unroll
-          for (int g = 0; g < 16; ++g) cnt_s[32 * w + (g & 3) + 8 * (g >> 2) + 4 * h] = cntr[g];
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's appends have landed
-        for (int rr = 0; rr < 32; ++rr) {
-          const int rl = 32 * w + rr;
-          const int c = cnt_s[rl];
-          if (c > kCap - kBN) {  // wave-uniform
-            int nc;
-            float nth;
-            compact_row(a.cand + (size_t)(q0 + rl) * kCap, min(c, kCap), a.k_eff, lane, &nc, &nth);
-            if (kDbg == 2 && lane == 0) atomicAdd(&a.dbg[1], 1ull);
-            const bool ovf = nc > kCap - kBN;  // more keys inside the window than the buffer can take
-            if (lane == 0) {
-              cnt_s[rl] = nc;
-              theta_s[rl] = ovf ? INFINITY : nth;
-              if (ovf) a.flags[q0 + rl] |= 1;
-            }
-          }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const int rl = 32 * w + (g & 3) + 8 * (g >> 2) + 4 * h;
-          cntr[g] = cnt_s[rl];
-          thr[g] = theta_s[rl];
-        }
-      }
-    }
+    if (t + 1 < a.tile1) store_tile(buf ^ 1);
     __syncthreads();
   }
-  if (r32 == 0) {
+  if (kDbg != 1 && r32 == 0) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const int rl = 32 * w + (g & 3) + 8 * (g >> 2) + 4 * h;
-      if (q0 + rl < a.nq) {
-        a.cnt[q0 + rl] = min(cntr[g], kCap);
-        a.theta[q0 + rl] = thr[g];
+      const int rl = q0 + 32 * w + (g & 3) + 8 * (g >> 2) + 4 * h;
+      if (rl < a.nq) {
+        a.cnt[rl] = min(cntr[g], kCap);
+        if (cntr[g] > kCap) a.flags[rl] |= 1;  // the super-step produced more candidates than the buffer holds
       }
     }
+  }
+}
+
+__global__ void k_init_rows(int32_t *cnt, float *theta, int32_t *flags, int nq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nq) {
+    cnt[i] = 0;
+    theta[i] = kThetaInit;
+    flags[i] = 0;
   }
 }
 
@@ -461,7 +442,7 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
   hipLaunchKernelGGL(k_to_f16, dim3(b1), dim3(256), 0, s, What, nullptr, n, keep, 0, Wb);
   hipLaunchKernelGGL(k_to_f16, dim3(b2), dim3(256), 0, s, What, queries, nq, nullptr, 1, Qb);
   ANIREC_HIP_CHECK(hipGetLastError());
-  ANIREC_HIP_CHECK(hipMemsetAsync(flags_out, 0, (size_t)nq * 4, s));
+  hipLaunchKernelGGL(k_init_rows, dim3((nq + 255) / 256), dim3(256), 0, s, cnt, theta, flags_out, nq);
   CandArgs ca;
   ca.Qb = (const uint4 *)Qb;
   ca.Wb = (const uint4 *)Wb;
@@ -473,25 +454,44 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
   ca.theta = theta;
   ca.flags = flags_out;
   ca.dbg = nullptr;
-  {
-    const char *dbg = getenv("ANIREC_TOPK_DEBUG");
-    const int mode = dbg ? atoi(dbg) : 0;
-    const dim3 grid((nq + kBM - 1) / kBM);
+  const char *dbg = getenv("ANIREC_TOPK_DEBUG");
+  const int mode = dbg ? atoi(dbg) : 0;
+  if (mode == 2) {
+    ca.dbg = (unsigned long long *)p;  // the 256 spare bytes at the end of the workspace
+    (void)hipMemsetAsync(p, 0, 16, s);
+  }
+  // Super-steps of the key stream: thresholds are fixed inside a launch and refreshed between
+  // launches; each super-step doubles the number of keys seen, so a row gains about k_eff new
+  // candidates per super-step (the first one, with no threshold yet, must fit the buffer).
+  const int ntiles = (n + kBN - 1) / kBN;
+  const dim3 grid((nq + kBM - 1) / kBM);
+  int n_launch = 0;
+  const char *gp = getenv("ANIREC_TOPK_GROWTH");
+  const int growth_pct = gp ? atoi(gp) : 100;
+  for (int t0 = 0, step = (kCap - kBN) / kBN; t0 < ntiles;) {
+    const int t1 = t0 + step < ntiles ? t0 + step : ntiles;
+    ca.tile0 = t0;
+    ca.tile1 = t1;
     if (mode == 1)
       hipLaunchKernelGGL(k_cand<1>, grid, dim3(256), 0, s, ca);
-    else if (mode == 2) {  // counters land in the first 16 bytes of cnt (debug only)
-      ca.dbg = (unsigned long long *)p;  // the 256 spare bytes at the end of the workspace
-      (void)hipMemsetAsync(p, 0, 16, s);
+    else if (mode == 2)
       hipLaunchKernelGGL(k_cand<2>, grid, dim3(256), 0, s, ca);
-      unsigned long long hv[2] = {0, 0};
-      (void)hipMemcpyAsync(hv, p, 16, hipMemcpyDeviceToHost, s);
-      (void)hipStreamSynchronize(s);
-      fprintf(stderr, "[anirec topk debug] nq=%d n=%d appends/row=%.1f compactions/row=%.2f\n", nq, n,
-              (double)hv[0] / nq, (double)hv[1] / nq);
-    } else
+    else
       hipLaunchKernelGGL(k_cand<0>, grid, dim3(256), 0, s, ca);
+    if (t1 < ntiles) hipLaunchKernelGGL(k_refresh, dim3(nq), dim3(64), 0, s, ca);
+    ANIREC_HIP_CHECK(hipGetLastError());
+    step = (int)((long long)t1 * growth_pct / 100);  // next super-step: growth_pct % of the tiles seen so far
+    if (step < 1) step = 1;
+    t0 = t1;
+    ++n_launch;
   }
-  ANIREC_HIP_CHECK(hipGetLastError());
+  if (mode == 2) {
+    unsigned long long hv[2] = {0, 0};
+    (void)hipMemcpyAsync(hv, p, 16, hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    fprintf(stderr, "[anirec topk debug] nq=%d n=%d appends/row=%.1f super-steps=%d\n", nq, n,
+            (double)hv[0] / nq, n_launch);
+  }
   RerankArgs ra;
   ra.What = What;
   ra.Qf = nullptr;
