@@ -45,6 +45,7 @@ constexpr float kThetaInit = -4.0f;  // below every cosine; finite so that (scor
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t f2key(float s) {  // order preserving, NaN -> 0 (never selected)
   if (s != s) return 0u;
@@ -60,11 +61,16 @@ __device__ __forceinline__ float key2f(uint32_t u) {
 // fp32 [rows][128] (optionally gathered through `rows`) -> fp16, round to nearest even
 // Key rows excluded by the caller's mask become NaN rows: their scores are NaN, which never compares
 // >= 0 and is ignored by v_max — the filter needs no per-key test (and no load) in the hot loop.
-__global__ __launch_bounds__(256) void k_to_f16(const float *W, const int32_t *rows, int n,
+// rows n .. n_pad-1 of the output are NaN rows (key-tile padding).
+__global__ __launch_bounds__(256) void k_to_f16(const float *W, const int32_t *rows, int n, int n_pad,
                                                 const uint8_t *keep, int zero_nan, _Float16 *out) {
   const int l = threadIdx.x & 31;
   const int nhw = gridDim.x * 8;
-  for (int r = blockIdx.x * 8 + (threadIdx.x >> 5); r < n; r += nhw) {
+  for (int r = blockIdx.x * 8 + (threadIdx.x >> 5); r < n_pad; r += nhw) {
+    if (r >= n) {
+      reinterpret_cast<uint2 *>(out)[(size_t)r * kRowVec + l] = make_uint2(0x7E007E00u, 0x7E007E00u);
+      continue;
+    }
     const int src = rows ? rows[r] : r;
     const float4 x = reinterpret_cast<const float4 *>(W)[(size_t)src * kRowVec + l];
     _Float16 o[4] = {(_Float16)x.x, (_Float16)x.y, (_Float16)x.z, (_Float16)x.w};
@@ -156,95 +162,126 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
       qa[ks] = *reinterpret_cast<f16x8 *>(&v);
     }
   }
-  uint4 stage[8];
+  // Key tiles: Wb is padded with NaN rows to whole tiles (see the host code), so the tile loads need
+  // no bounds test: a wave-uniform base plus eight fixed per-thread offsets.
+  u32x4 stage[8];
+  const uint32_t voff = (uint32_t)tid * 16u;
   auto load_tile = [&](int t) {
+    const char *base = reinterpret_cast<const char *>(a.Wb) + (size_t)t * (kBN * 256);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = tid + 256 * i;  // chunk id: key = c >> 4, chunk = c & 15
-      const int key = t * kBN + (c >> 4);
-      // keys past the end of the table are NaN rows (never candidates)
-      stage[i] = key < a.n ? a.Wb[(size_t)key * 16 + (c & 15)]
-                           : make_uint4(0x7E007E00u, 0x7E007E00u, 0x7E007E00u, 0x7E007E00u);
-    }
+    for (int i = 0; i < 8; ++i) stage[i] = *reinterpret_cast<const u32x4 *>(base + (voff + 4096u * i));
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int c = tid + 256 * i;
+      const int c = tid + 256 * i;  // chunk id: key = c >> 4, chunk = c & 15
       const int key = c >> 4, ch = c & 15;
-      Ks[buf][key * 16 + (ch ^ (key & 15))] = stage[i];
+      *reinterpret_cast<u32x4 *>(&Ks[buf][key * 16 + (ch ^ (key & 15))]) = stage[i];
     }
   };
+  const int nt = a.tile1 - a.tile0;
   load_tile(a.tile0);
   store_tile(0);
+  if (nt > 1) load_tile(a.tile0 + 1);
 
   // Accumulator register g of a 32x32 block belongs to query row (g&3) + 8(g>>2) + 4h of the wave's
   // 32 rows: the rows are private to the wave, so their thresholds and buffer counts live in
   // registers (replicated over the 32 lanes of a half-wave) — no LDS, no atomics in the loop.
-  float thr[16];
+  f32x16 nthr;  // -theta of the 16 rows: loop-invariant C-in of every MFMA chain (no per-tile copies)
   int cntr[16];
   uint32_t rowoff[16];  // byte offset of the row's buffer (nq*kCap*8 < 2^32 is checked on the host)
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
     const int rl = q0 + 32 * w + (g & 3) + 8 * (g >> 2) + 4 * h;
     const bool live = rl < a.nq;
-    thr[g] = live ? a.theta[rl] : INFINITY;
+    nthr[g] = live ? -a.theta[rl] : -INFINITY;
     cntr[g] = live ? a.cnt[rl] : 0;
     rowoff[g] = (uint32_t)rl * (uint32_t)(kCap * 8);
   }
+  // LDS read addresses of the eight B fragments: (cb*32 + r32) & 15 == r32 & 15, so the swizzled chunk
+  // index depends only on the lane; block and buffer are compile-time / scalar offsets
+  const f16x8 *kb[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+    kb[ks] = reinterpret_cast<const f16x8 *>(&Ks[0][r32 * 16 + ((2 * ks + h) ^ (r32 & 15))]);
   const uint32_t lt32 = (1u << r32) - 1u;
   char *const cand_bytes = reinterpret_cast<char *>(a.cand);
+  // Touch the per-row registers here so the loads above are waited for BEFORE the loop: otherwise the
+  // compiler parks an s_waitcnt vmcnt(0) at their first use inside the append path, where it also
+  // waits for the key-tile prefetch that is meant to stay in flight under the MFMAs.
+#pragma unroll
+  for (int g = 0; g < 16; ++g) asm volatile("" ::"v"(cntr[g]), "v"(nthr[g]));
   __syncthreads();
 
-  for (int t = a.tile0; t < a.tile1; ++t) {
-    const int buf = (t - a.tile0) & 1;
-    if (t + 1 < a.tile1) load_tile(t + 1);  // global loads in flight under the MFMAs
-    // One 32x32 block at a time: 8 chained MFMAs (C-in = -theta, so the chain leaves score - theta and
-    // a candidate is simply acc >= 0), then that block's filter.
+  // Software pipeline over 32x32 blocks (4 per key tile).  Stage j filters block j while the matrix
+  // core works on block j+1 of the SAME wave (a second accumulator), and fetches the B fragments of
+  // block j+2 from LDS: the two MFMAs of a quarter are separated by that quarter's VALU test, so a
+  // dependent MFMA never stalls the wave and the filter never waits for an accumulator.
+  f16x8 bv[8];
+  auto fetch = [&](int ks, int buf, int cb) { bv[ks] = kb[ks][(buf * kBN + cb * 32) * 16]; };
+  auto mma = [&](int ks, const f32x16 &c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[ks], bv[ks], c, 0, 0, 0);
+  };
+  // cur: finished chain (score - theta) of block `key`; nxt: chain being issued from bv;
+  // (fbuf, fcb): block whose fragments replace bv as they are consumed
+  auto stage_fn = [&](const f32x16 &cur, f32x16 &nxt, int key, int fbuf, int fcb) {
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-      f32x16 acc;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) acc[g] = -thr[g];
-      const int krow = cb * 32 + r32;
-      uint4 bv[8];
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) bv[ks] = Ks[buf][krow * 16 + ((2 * ks + h) ^ (krow & 15))];
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[ks], *reinterpret_cast<const f16x8 *>(&bv[ks]), acc, 0, 0, 0);
-      if (kDbg == 1) {
-        asm volatile("" ::"v"(acc));
-        continue;
-      }
-      const int key = t * kBN + cb * 32 + r32;
+    for (int qd = 0; qd < 4; ++qd) {
+      nxt = mma(2 * qd, qd == 0 ? nthr : nxt);
+      __builtin_amdgcn_sched_barrier(0);
       // hierarchical reject: one max over 4 accumulator registers (256 scores) + a ballot
       // (plain fmaxf: an inline-asm v_max3 reading MFMA results would bypass hipcc's MFMA->VALU
       // hazard padding and was observed to miss candidates)
+      float mq = 0.f;
+      if (kDbg == 1 && qd == 0) asm volatile("" ::"v"(cur));  // keep the chains alive without a filter
+      if (kDbg != 1) mq = fmaxf(fmaxf(fmaxf(cur[4 * qd], cur[4 * qd + 1]), cur[4 * qd + 2]), cur[4 * qd + 3]);
+      __builtin_amdgcn_sched_barrier(0);
+      nxt = mma(2 * qd + 1, nxt);
+      fetch(2 * qd, fbuf, fcb);
+      fetch(2 * qd + 1, fbuf, fcb);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kDbg != 1 && __ballot(mq >= 0.f)) {
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const float mq = fmaxf(fmaxf(fmaxf(acc[4 * qd], acc[4 * qd + 1]), acc[4 * qd + 2]), acc[4 * qd + 3]);
-        if (__ballot(mq >= 0.f)) {
-#pragma unroll
-          for (int gg = 0; gg < 4; ++gg) {
-            const int g = 4 * qd + gg;
-            const unsigned long long mk = __ballot(acc[g] >= 0.f);
-            if (mk) {  // wave-uniform
-              const uint32_t mh = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
-              const uint32_t pos = (uint32_t)cntr[g] + __popc(mh & lt32);
-              if (acc[g] >= 0.f && pos < (uint32_t)kCap)
-                *reinterpret_cast<uint2 *>(cand_bytes + (rowoff[g] + pos * 8u)) =
-                    make_uint2(__float_as_uint(acc[g] + thr[g]), (uint32_t)key);
-              cntr[g] += __popc(mh);
-              if (kDbg == 2 && lane == 0) atomicAdd(&a.dbg[0], (unsigned long long)__popcll(mk));
-            }
+        for (int gg = 0; gg < 4; ++gg) {
+          const int g = 4 * qd + gg;
+          const unsigned long long mk = __ballot(cur[g] >= 0.f);
+          if (mk) {  // wave-uniform
+            const uint32_t mh = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
+            const uint32_t pos = (uint32_t)cntr[g] + __popc(mh & lt32);
+            if (cur[g] >= 0.f && pos < (uint32_t)kCap)
+              *reinterpret_cast<uint2 *>(cand_bytes + (rowoff[g] + pos * 8u)) =
+                  make_uint2(__float_as_uint(cur[g] - nthr[g]), (uint32_t)key);
+            cntr[g] += __popc(mh);
+            if (kDbg == 2 && lane == 0) atomicAdd(&a.dbg[0], (unsigned long long)__popcll(mk));
           }
         }
       }
     }
-    // next tile into the free LDS buffer (its readers finished at the previous barrier)
-    if (t + 1 < a.tile1) store_tile(buf ^ 1);
+  };
+
+  // prologue: chain of block (tile0, 0), fragments of block (tile0, 1)
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) fetch(ks, 0, 0);
+  acc0 = mma(0, nthr);
+#pragma unroll
+  for (int ks = 1; ks < 8; ++ks) acc0 = mma(ks, acc0);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) fetch(ks, 0, 1);
+
+  for (int it = 0; it < nt; ++it) {
+    const int buf = it & 1;
+    const int key = (a.tile0 + it) * kBN + r32;
+    stage_fn(acc0, acc1, key, buf, 2);       // filter block 0 | MFMA block 1 | fetch block 2
+    stage_fn(acc1, acc0, key + 32, buf, 3);  // filter block 1 | MFMA block 2 | fetch block 3
+    // The other LDS buffer was last read (fetched) before the previous barrier: refill it with the
+    // next tile now, so that the fetches of the next two stages can cross the tile boundary.
+    if (it + 1 < nt) store_tile(buf ^ 1);
     __syncthreads();
+    if (it + 2 < nt) load_tile(a.tile0 + it + 2);  // global loads in flight for a whole tile
+    // on the last tile the "next tile" blocks are stale LDS: computed and thrown away
+    stage_fn(acc0, acc1, key + 64, buf ^ 1, 0);  // filter block 2 | MFMA block 3 | fetch next tile's block 0
+    stage_fn(acc1, acc0, key + 96, buf ^ 1, 1);  // filter block 3 | MFMA next block 0 | fetch next block 1
   }
   if (kDbg != 1 && r32 == 0) {
 #pragma unroll
@@ -407,11 +444,14 @@ using namespace anirec;
 
 extern "C" {
 
-// workspace: Wb (n*256 B) | Qb (nq*256 B) | cand (nq*kCap*8) | cnt, theta (nq*4 each)
+// Wb holds whole key tiles: rows n .. padded_keys(n)-1 are NaN rows (never candidates)
+static inline size_t padded_keys(int32_t n) { return ((size_t)n + kBN - 1) / kBN * kBN; }
+
+// workspace: Wb (padded_keys(n)*256 B) | Qb (nq*256 B) | cand (nq*kCap*8) | cnt, theta (nq*4 each)
 size_t anirec_topk_mfma_workspace_bytes(int32_t n, int32_t nq) {
   if (n < 1 || nq < 1) return 0;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-  return al((size_t)n * 256) + al((size_t)nq * 256) + al((size_t)nq * kCap * 8) + 2 * al((size_t)nq * 4) + 256;
+  return al(padded_keys(n) * 256) + al((size_t)nq * 256) + al((size_t)nq * kCap * 8) + 2 * al((size_t)nq * 4) + 256;
 }
 
 int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries, int32_t nq,
@@ -427,7 +467,7 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   char *p = (char *)workspace;
   _Float16 *Wb = (_Float16 *)p;
-  p += al((size_t)n * 256);
+  p += al(padded_keys(n) * 256);
   _Float16 *Qb = (_Float16 *)p;
   p += al((size_t)nq * 256);
   uint2 *cand = (uint2 *)p;
@@ -439,8 +479,8 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
   int b1 = (n + 7) / 8, b2 = (nq + 7) / 8;
   if (b1 > 8192) b1 = 8192;
   if (b2 > 8192) b2 = 8192;
-  hipLaunchKernelGGL(k_to_f16, dim3(b1), dim3(256), 0, s, What, nullptr, n, keep, 0, Wb);
-  hipLaunchKernelGGL(k_to_f16, dim3(b2), dim3(256), 0, s, What, queries, nq, nullptr, 1, Qb);
+  hipLaunchKernelGGL(k_to_f16, dim3(b1), dim3(256), 0, s, What, nullptr, n, (int)padded_keys(n), keep, 0, Wb);
+  hipLaunchKernelGGL(k_to_f16, dim3(b2), dim3(256), 0, s, What, queries, nq, nq, nullptr, 1, Qb);
   ANIREC_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(k_init_rows, dim3((nq + 255) / 256), dim3(256), 0, s, cnt, theta, flags_out, nq);
   CandArgs ca;
