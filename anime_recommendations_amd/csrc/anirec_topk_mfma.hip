@@ -102,16 +102,14 @@ struct CandArgs {
 // everything below it is dropped from the buffer.  Fully parallel over the rows (no workgroup of the
 // MFMA kernel ever waits for a compaction).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_refresh(CandArgs a) {
-  const int lane = threadIdx.x;
-  const int row = blockIdx.x;
-  uint2 *cand_row = a.cand + (size_t)row * kCap;
-  const int c = min(a.cnt[row], kCap);
-  if (c < a.k_eff) return;  // not enough candidates yet (tiny tables): keep the threshold
-  uint2 en[kCap / 64];
-  uint32_t u[kCap / 64];
+// kSlots = ceil(entries / 64) register slots per lane: after the first super-step a row holds about
+// 2 k_eff entries, so the 32-step radix select runs over 1 slot (k = 10) or 4 (k = 100), not 8.
+template <int kSlots>
+__device__ __forceinline__ void refresh_row(const CandArgs &a, uint2 *cand_row, int row, int c, int lane) {
+  uint2 en[kSlots];
+  uint32_t u[kSlots];
 #pragma unroll
-  for (int j = 0; j < kCap / 64; ++j) {
+  for (int j = 0; j < kSlots; ++j) {
     const int e = lane + 64 * j;
     en[j] = e < c ? cand_row[e] : make_uint2(0u, 0u);
     u[j] = e < c ? f2key(__uint_as_float(en[j].x)) : 0u;
@@ -121,14 +119,14 @@ __global__ __launch_bounds__(64) void k_refresh(CandArgs a) {
     const uint32_t trial = prefix | (1u << bit);
     int cge = 0;  // wave-uniform: ballots + scalar popcounts, no cross-lane shuffles
 #pragma unroll
-    for (int j = 0; j < kCap / 64; ++j) cge += __popcll(__ballot(u[j] >= trial));
+    for (int j = 0; j < kSlots; ++j) cge += __popcll(__ballot(u[j] >= trial));
     if (cge >= a.k_eff) prefix = trial;
   }
   const float th = key2f(prefix) - 2.f * kEpsMfma;
   int nc = 0;
   const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
-  for (int j = 0; j < kCap / 64; ++j) {
+  for (int j = 0; j < kSlots; ++j) {
     const bool kp = u[j] != 0u && __uint_as_float(en[j].x) >= th;
     const unsigned long long m = __ballot(kp);
     if (kp) cand_row[nc + __popcll(m & lt)] = en[j];  // nc + rank < c <= kCap
@@ -138,6 +136,22 @@ __global__ __launch_bounds__(64) void k_refresh(CandArgs a) {
     a.cnt[row] = nc;
     a.theta[row] = th;
   }
+}
+
+__global__ __launch_bounds__(64) void k_refresh(CandArgs a) {
+  const int lane = threadIdx.x;
+  const int row = blockIdx.x;
+  uint2 *cand_row = a.cand + (size_t)row * kCap;
+  const int c = min(a.cnt[row], kCap);
+  if (c < a.k_eff) return;  // not enough candidates yet (tiny tables): keep the threshold
+  if (c <= 64)
+    refresh_row<1>(a, cand_row, row, c, lane);
+  else if (c <= 128)
+    refresh_row<2>(a, cand_row, row, c, lane);
+  else if (c <= 256)
+    refresh_row<4>(a, cand_row, row, c, lane);
+  else
+    refresh_row<kCap / 64>(a, cand_row, row, c, lane);
 }
 
 // ------------------------------------------------------------------------------------
@@ -233,14 +247,14 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
       // (plain fmaxf: an inline-asm v_max3 reading MFMA results would bypass hipcc's MFMA->VALU
       // hazard padding and was observed to miss candidates)
       float mq = 0.f;
-      if (kDbg == 1 && qd == 0) asm volatile("" ::"v"(cur));  // keep the chains alive without a filter
-      if (kDbg != 1) mq = fmaxf(fmaxf(fmaxf(cur[4 * qd], cur[4 * qd + 1]), cur[4 * qd + 2]), cur[4 * qd + 3]);
+      if ((kDbg == 1 || kDbg >= 3) && qd == 0) asm volatile("" ::"v"(cur));  // keep the chains alive without a filter
+      if (kDbg != 1 && kDbg < 3) mq = fmaxf(fmaxf(fmaxf(cur[4 * qd], cur[4 * qd + 1]), cur[4 * qd + 2]), cur[4 * qd + 3]);
       __builtin_amdgcn_sched_barrier(0);
       nxt = mma(2 * qd + 1, nxt);
       fetch(2 * qd, fbuf, fcb);
-      fetch(2 * qd + 1, fbuf, fcb);
+      if (kDbg != 4) fetch(2 * qd + 1, fbuf, fcb);
       __builtin_amdgcn_sched_barrier(0);
-      if (kDbg != 1 && __ballot(mq >= 0.f)) {
+      if (kDbg != 1 && kDbg < 3 && __ballot(mq >= 0.f)) {
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) {
           const int g = 4 * qd + gg;
@@ -276,14 +290,15 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
     stage_fn(acc1, acc0, key + 32, buf, 3);  // filter block 1 | MFMA block 2 | fetch block 3
     // The other LDS buffer was last read (fetched) before the previous barrier: refill it with the
     // next tile now, so that the fetches of the next two stages can cross the tile boundary.
-    if (it + 1 < nt) store_tile(buf ^ 1);
-    __syncthreads();
+    if (kDbg != 3 && it + 1 < nt) store_tile(buf ^ 1);
+    if (kDbg == 3) asm volatile("" ::"v"(stage[0]), "v"(stage[1]), "v"(stage[2]), "v"(stage[3]), "v"(stage[4]), "v"(stage[5]), "v"(stage[6]), "v"(stage[7]));
+    if (kDbg != 5) __syncthreads();
     if (it + 2 < nt) load_tile(a.tile0 + it + 2);  // global loads in flight for a whole tile
     // on the last tile the "next tile" blocks are stale LDS: computed and thrown away
     stage_fn(acc0, acc1, key + 64, buf ^ 1, 0);  // filter block 2 | MFMA block 3 | fetch next tile's block 0
     stage_fn(acc1, acc0, key + 96, buf ^ 1, 1);  // filter block 3 | MFMA next block 0 | fetch next block 1
   }
-  if (kDbg != 1 && r32 == 0) {
+  if (kDbg != 1 && kDbg < 3 && r32 == 0) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const int rl = q0 + 32 * w + (g & 3) + 8 * (g >> 2) + 4 * h;
@@ -514,6 +529,12 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
     ca.tile1 = t1;
     if (mode == 1)
       hipLaunchKernelGGL(k_cand<1>, grid, dim3(256), 0, s, ca);
+    else if (mode == 3)
+      hipLaunchKernelGGL(k_cand<3>, grid, dim3(256), 0, s, ca);
+    else if (mode == 4)
+      hipLaunchKernelGGL(k_cand<4>, grid, dim3(256), 0, s, ca);
+    else if (mode == 5)
+      hipLaunchKernelGGL(k_cand<5>, grid, dim3(256), 0, s, ca);
     else if (mode == 2)
       hipLaunchKernelGGL(k_cand<2>, grid, dim3(256), 0, s, ca);
     else
