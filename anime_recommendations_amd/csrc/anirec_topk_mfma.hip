@@ -1,15 +1,17 @@
 // All-pairs cosine top-k on the gfx950 matrix cores.
 //
 // Replaces the reference's per-query  np.dot(W_hat, W_hat[q]) + np.argsort  (similar_anime.py:404-408,
-// similar_users.py:293-296) at BASELINE scale (every row a query, top-100 of 18 k / 350 k rows) without
+// similar_users.py:293-296) at BASELINE scale (every row a query, top-k of 18 k / 350 k rows) without
 // ever materialising the n x n score matrix.
 //
 // Three kernels:
-//   k_cand    one SUPER-STEP of the key stream: v_mfma_f32_32x32x16_f16 scores of 128 queries x a range
+//   k_cand    one SUPER-STEP of the key stream: v_mfma_f32_16x16x32_f16 scores of 128 queries x a range
 //             of key tiles per workgroup (fp16 operands: the bf16 MFMA rate with 8x smaller rounding
-//             error).  Each query row has a candidate buffer in HBM/L2 and, in registers, a count and a
-//             threshold theta that is FIXED for the launch and folded into the MFMA accumulator
-//             (C-in = -theta): a candidate is `acc >= 0`; ranks come from wave ballots (no atomics).
+//             error; the 16x16x32 shape because the chip holds a higher clock on it).  Each query row
+//             has a candidate buffer in HBM/L2 and, in registers, a count and a threshold theta that is
+//             FIXED for the launch and folded into the MFMA accumulator (C-in = -theta): a candidate
+//             is `acc >= 0`; ranks come from wave ballots (no atomics).  The filter of one 32x32 block
+//             runs under the MFMAs of the next (software pipeline inside each wave).
 //   k_refresh between super-steps, one wave per row: tau = k-th largest MFMA score seen so far is a
 //             lower bound of the final one, so theta = tau - 2 eps keeps every key that can still reach
 //             the exact top-k; the buffer is compacted.  Super-steps double the keys seen, so a row
@@ -46,6 +48,7 @@ constexpr float kThetaInit = -4.0f;  // below every cosine; finite so that (scor
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t f2key(float s) {  // order preserving, NaN -> 0 (never selected)
   if (s != s) return 0u;
@@ -158,22 +161,26 @@ __global__ __launch_bounds__(64) void k_refresh(CandArgs a) {
 // k_cand: one super-step.  128 query rows per workgroup (4 waves x 32 rows, fragments in registers),
 // key tiles of 128 rows double-buffered in XOR-swizzled LDS, thresholds FIXED for the launch.
 // ------------------------------------------------------------------------------------
-template <int kDbg>  // 0: product; 1: no epilogue (timing experiments only); 2: count appends
+template <int kDbg>  // 0: product; 1: no filter (timing experiments only); 2: count appends
 __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
   __shared__ __attribute__((aligned(16))) uint4 Ks[2][kBN * 16];  // 2 x 32 KB
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int r32 = lane & 31, h = lane >> 5;
+  const int c16 = lane & 15, gq = lane >> 4;
   const int q0 = blockIdx.x * kBM;
 
-  // query fragments: A[row r32][k = 16*ks + 8*h + j]
-  f16x8 qa[8];
-  {
-    const int qrow = q0 + 32 * w + r32;
+  // v_mfma_f32_16x16x32_f16 (the shape the chip clocks higher on): a lane holds A[row c16][k = 8 gq + j],
+  // B[k = 8 gq + j][col c16], C[row 4 gq + i][col c16].  The wave owns 32 query rows = 2 row blocks (rb);
+  // a 32-key block is 2 key blocks (nb); K = 128 is 4 steps (kk) of 32 -> 16 MFMAs in 4 independent
+  // accumulation chains per 32x32 block.
+  f16x8 qa[2][4];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (qrow < a.nq) v = a.Qb[(size_t)qrow * 16 + 2 * ks + h];
-      qa[ks] = *reinterpret_cast<f16x8 *>(&v);
+  for (int rb = 0; rb < 2; ++rb) {
+    const int qrow = q0 + 32 * w + 16 * rb + c16;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (qrow < a.nq) v = *reinterpret_cast<const u32x4 *>(&a.Qb[(size_t)qrow * 16 + 4 * kk + gq]);
+      qa[rb][kk] = __builtin_bit_cast(f16x8, v);
     }
   }
   // Key tiles: Wb is padded with NaN rows to whole tiles (see the host code), so the tile loads need
@@ -198,74 +205,87 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
   store_tile(0);
   if (nt > 1) load_tile(a.tile0 + 1);
 
-  // Accumulator register g of a 32x32 block belongs to query row (g&3) + 8(g>>2) + 4h of the wave's
-  // 32 rows: the rows are private to the wave, so their thresholds and buffer counts live in
-  // registers (replicated over the 32 lanes of a half-wave) — no LDS, no atomics in the loop.
-  f32x16 nthr;  // -theta of the 16 rows: loop-invariant C-in of every MFMA chain (no per-tile copies)
-  int cntr[16];
-  uint32_t rowoff[16];  // byte offset of the row's buffer (nq*kCap*8 < 2^32 is checked on the host)
+  // Accumulator register i of block (rb, nb) belongs to query row 16 rb + 4 gq + i of the wave's 32
+  // rows: the rows are private to the wave, so their thresholds and buffer counts live in registers
+  // (replicated over the 16 lanes of a quarter-wave) — no LDS, no atomics in the loop.
+  f32x4 nthr[2];  // -theta: loop-invariant C-in of the MFMA chains (no per-tile copies)
+  int cntr[2][4];
+  uint32_t rowoff[2][4];  // byte offset of the row's buffer (nq*kCap*8 < 2^32 is checked on the host)
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const int rl = q0 + 32 * w + (g & 3) + 8 * (g >> 2) + 4 * h;
-    const bool live = rl < a.nq;
-    nthr[g] = live ? -a.theta[rl] : -INFINITY;
-    cntr[g] = live ? a.cnt[rl] : 0;
-    rowoff[g] = (uint32_t)rl * (uint32_t)(kCap * 8);
-  }
-  // LDS read addresses of the eight B fragments: (cb*32 + r32) & 15 == r32 & 15, so the swizzled chunk
-  // index depends only on the lane; block and buffer are compile-time / scalar offsets
-  const f16x8 *kb[8];
+  for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks)
-    kb[ks] = reinterpret_cast<const f16x8 *>(&Ks[0][r32 * 16 + ((2 * ks + h) ^ (r32 & 15))]);
-  const uint32_t lt32 = (1u << r32) - 1u;
+    for (int i = 0; i < 4; ++i) {
+      const int rl = q0 + 32 * w + 16 * rb + 4 * gq + i;
+      const bool live = rl < a.nq;
+      nthr[rb][i] = live ? -a.theta[rl] : -INFINITY;
+      cntr[rb][i] = live ? a.cnt[rl] : 0;
+      rowoff[rb][i] = (uint32_t)rl * (uint32_t)(kCap * 8);
+    }
+  // LDS read addresses of the B fragments: key row 32 cb + 16 nb + c16 has (row & 15) == c16, so the
+  // swizzled chunk index depends only on (kk, lane); buffer, cb and nb are constant offsets
+  const f16x8 *kb[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+    kb[kk] = reinterpret_cast<const f16x8 *>(&Ks[0][c16 * 16 + ((4 * kk + gq) ^ c16)]);
+  const uint32_t lt16 = (1u << c16) - 1u;
+  const int sh16 = 16 * gq;
   char *const cand_bytes = reinterpret_cast<char *>(a.cand);
   // Touch the per-row registers here so the loads above are waited for BEFORE the loop: otherwise the
   // compiler parks an s_waitcnt vmcnt(0) at their first use inside the append path, where it also
   // waits for the key-tile prefetch that is meant to stay in flight under the MFMAs.
 #pragma unroll
-  for (int g = 0; g < 16; ++g) asm volatile("" ::"v"(cntr[g]), "v"(nthr[g]));
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(cntr[rb][i]), "v"(nthr[rb][i]));
   __syncthreads();
 
   // Software pipeline over 32x32 blocks (4 per key tile).  Stage j filters block j while the matrix
-  // core works on block j+1 of the SAME wave (a second accumulator), and fetches the B fragments of
-  // block j+2 from LDS: the two MFMAs of a quarter are separated by that quarter's VALU test, so a
-  // dependent MFMA never stalls the wave and the filter never waits for an accumulator.
-  f16x8 bv[8];
-  auto fetch = [&](int ks, int buf, int cb) { bv[ks] = kb[ks][(buf * kBN + cb * 32) * 16]; };
-  auto mma = [&](int ks, const f32x16 &c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[ks], bv[ks], c, 0, 0, 0);
-  };
-  // cur: finished chain (score - theta) of block `key`; nxt: chain being issued from bv;
-  // (fbuf, fcb): block whose fragments replace bv as they are consumed
-  auto stage_fn = [&](const f32x16 &cur, f32x16 &nxt, int key, int fbuf, int fcb) {
+  // core works on block j+1 of the SAME wave (a second accumulator set), and fetches the B fragments
+  // of block j+2 from LDS as the MFMAs consume the current ones.
+  f16x8 bv[2][4];
+  auto fetch = [&](int kk, int buf, int cb) {
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      nxt = mma(2 * qd, qd == 0 ? nthr : nxt);
+    for (int nb = 0; nb < 2; ++nb) bv[nb][kk] = kb[kk][(buf * kBN + cb * 32 + nb * 16) * 16];
+  };
+  struct Acc { f32x4 c[2][2]; };  // [rb][nb]
+  auto mma_step = [&](Acc &x, int kk) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+        x.c[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[rb][kk], bv[nb][kk], kk == 0 ? nthr[rb] : x.c[rb][nb], 0, 0, 0);
+  };
+  // cur: finished chains (score - theta) of the 32-key block starting at key0; nxt: chains being
+  // issued from bv; (fbuf, fcb): block whose fragments replace bv as they are consumed
+  auto stage_fn = [&](const Acc &cur, Acc &nxt, int key0, int fbuf, int fcb) {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {  // quarter qd: MFMA step kk = qd of the next block, filter (rb, nb) of this one
+      const int rb = qd >> 1, nb = qd & 1;
+      const f32x4 &cv = cur.c[rb][nb];
+      mma_step(nxt, qd);
       __builtin_amdgcn_sched_barrier(0);
-      // hierarchical reject: one max over 4 accumulator registers (256 scores) + a ballot
+      fetch(qd, fbuf, fcb);
+      // hierarchical reject: one max over the 4 accumulator registers (256 scores) + a ballot
       // (plain fmaxf: an inline-asm v_max3 reading MFMA results would bypass hipcc's MFMA->VALU
       // hazard padding and was observed to miss candidates)
-      float mq = 0.f;
-      if ((kDbg == 1 || kDbg >= 3) && qd == 0) asm volatile("" ::"v"(cur));  // keep the chains alive without a filter
-      if (kDbg != 1 && kDbg < 3) mq = fmaxf(fmaxf(fmaxf(cur[4 * qd], cur[4 * qd + 1]), cur[4 * qd + 2]), cur[4 * qd + 3]);
+      if (kDbg == 1) {
+        if (qd == 0) asm volatile("" ::"v"(cur.c[0][0]), "v"(cur.c[0][1]), "v"(cur.c[1][0]), "v"(cur.c[1][1]));
+        continue;
+      }
+      const float mq = fmaxf(fmaxf(fmaxf(cv[0], cv[1]), cv[2]), cv[3]);
       __builtin_amdgcn_sched_barrier(0);
-      nxt = mma(2 * qd + 1, nxt);
-      fetch(2 * qd, fbuf, fcb);
-      if (kDbg != 4) fetch(2 * qd + 1, fbuf, fcb);
-      __builtin_amdgcn_sched_barrier(0);
-      if (kDbg != 1 && kDbg < 3 && __ballot(mq >= 0.f)) {
+      if (__ballot(mq >= 0.f)) {
+        const int key = key0 + 16 * nb + c16;
 #pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-          const int g = 4 * qd + gg;
-          const unsigned long long mk = __ballot(cur[g] >= 0.f);
+        for (int i = 0; i < 4; ++i) {
+          const unsigned long long mk = __ballot(cv[i] >= 0.f);
           if (mk) {  // wave-uniform
-            const uint32_t mh = h ? (uint32_t)(mk >> 32) : (uint32_t)mk;
-            const uint32_t pos = (uint32_t)cntr[g] + __popc(mh & lt32);
-            if (cur[g] >= 0.f && pos < (uint32_t)kCap)
-              *reinterpret_cast<uint2 *>(cand_bytes + (rowoff[g] + pos * 8u)) =
-                  make_uint2(__float_as_uint(cur[g] - nthr[g]), (uint32_t)key);
-            cntr[g] += __popc(mh);
+            const uint32_t mh = (uint32_t)(mk >> sh16) & 0xFFFFu;  // the quarter-wave (= row) of this lane
+            const uint32_t pos = (uint32_t)cntr[rb][i] + __popc(mh & lt16);
+            if (cv[i] >= 0.f && pos < (uint32_t)kCap)
+              *reinterpret_cast<uint2 *>(cand_bytes + (rowoff[rb][i] + pos * 8u)) =
+                  make_uint2(__float_as_uint(cv[i] - nthr[rb][i]), (uint32_t)key);
+            cntr[rb][i] += __popc(mh);
             if (kDbg == 2 && lane == 0) atomicAdd(&a.dbg[0], (unsigned long long)__popcll(mk));
           }
         }
@@ -273,40 +293,40 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
     }
   };
 
-  // prologue: chain of block (tile0, 0), fragments of block (tile0, 1)
-  f32x16 acc0, acc1;
+  // prologue: chains of block (tile0, 0), fragments of block (tile0, 1)
+  Acc acc0, acc1;
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) fetch(ks, 0, 0);
-  acc0 = mma(0, nthr);
+  for (int kk = 0; kk < 4; ++kk) fetch(kk, 0, 0);
 #pragma unroll
-  for (int ks = 1; ks < 8; ++ks) acc0 = mma(ks, acc0);
+  for (int kk = 0; kk < 4; ++kk) mma_step(acc0, kk);
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) fetch(ks, 0, 1);
+  for (int kk = 0; kk < 4; ++kk) fetch(kk, 0, 1);
 
   for (int it = 0; it < nt; ++it) {
     const int buf = it & 1;
-    const int key = (a.tile0 + it) * kBN + r32;
-    stage_fn(acc0, acc1, key, buf, 2);       // filter block 0 | MFMA block 1 | fetch block 2
-    stage_fn(acc1, acc0, key + 32, buf, 3);  // filter block 1 | MFMA block 2 | fetch block 3
+    const int key0 = (a.tile0 + it) * kBN;
+    stage_fn(acc0, acc1, key0, buf, 2);       // filter block 0 | MFMA block 1 | fetch block 2
+    stage_fn(acc1, acc0, key0 + 32, buf, 3);  // filter block 1 | MFMA block 2 | fetch block 3
     // The other LDS buffer was last read (fetched) before the previous barrier: refill it with the
     // next tile now, so that the fetches of the next two stages can cross the tile boundary.
-    if (kDbg != 3 && it + 1 < nt) store_tile(buf ^ 1);
-    if (kDbg == 3) asm volatile("" ::"v"(stage[0]), "v"(stage[1]), "v"(stage[2]), "v"(stage[3]), "v"(stage[4]), "v"(stage[5]), "v"(stage[6]), "v"(stage[7]));
-    if (kDbg != 5) __syncthreads();
+    if (it + 1 < nt) store_tile(buf ^ 1);
+    __syncthreads();
     if (it + 2 < nt) load_tile(a.tile0 + it + 2);  // global loads in flight for a whole tile
     // on the last tile the "next tile" blocks are stale LDS: computed and thrown away
-    stage_fn(acc0, acc1, key + 64, buf ^ 1, 0);  // filter block 2 | MFMA block 3 | fetch next tile's block 0
-    stage_fn(acc1, acc0, key + 96, buf ^ 1, 1);  // filter block 3 | MFMA next block 0 | fetch next block 1
+    stage_fn(acc0, acc1, key0 + 64, buf ^ 1, 0);  // filter block 2 | MFMA block 3 | fetch next tile's block 0
+    stage_fn(acc1, acc0, key0 + 96, buf ^ 1, 1);  // filter block 3 | MFMA next block 0 | fetch next block 1
   }
-  if (kDbg != 1 && kDbg < 3 && r32 == 0) {
+  if (kDbg != 1 && c16 == 0) {
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const int rl = q0 + 32 * w + (g & 3) + 8 * (g >> 2) + 4 * h;
-      if (rl < a.nq) {
-        a.cnt[rl] = min(cntr[g], kCap);
-        if (cntr[g] > kCap) a.flags[rl] |= 1;  // the super-step produced more candidates than the buffer holds
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rl = q0 + 32 * w + 16 * rb + 4 * gq + i;
+        if (rl < a.nq) {
+          a.cnt[rl] = min(cntr[rb][i], kCap);
+          if (cntr[rb][i] > kCap) a.flags[rl] |= 1;  // the super-step produced more candidates than the buffer holds
+        }
       }
-    }
   }
 }
 
@@ -529,12 +549,7 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
     ca.tile1 = t1;
     if (mode == 1)
       hipLaunchKernelGGL(k_cand<1>, grid, dim3(256), 0, s, ca);
-    else if (mode == 3)
-      hipLaunchKernelGGL(k_cand<3>, grid, dim3(256), 0, s, ca);
-    else if (mode == 4)
-      hipLaunchKernelGGL(k_cand<4>, grid, dim3(256), 0, s, ca);
-    else if (mode == 5)
-      hipLaunchKernelGGL(k_cand<5>, grid, dim3(256), 0, s, ca);
+
     else if (mode == 2)
       hipLaunchKernelGGL(k_cand<2>, grid, dim3(256), 0, s, ca);
     else
