@@ -29,6 +29,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <vector>
+
 #include "anirec_dev.hpp"
 
 namespace anirec {
@@ -257,23 +259,36 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
   };
   // cur: finished chains (score - theta) of the 32-key block starting at key0; nxt: chains being
   // issued from bv; (fbuf, fcb): block whose fragments replace bv as they are consumed
+  auto mma1 = [&](Acc &x, int rb, int nb, int kk) {
+    x.c[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[rb][kk], bv[nb][kk], kk == 0 ? nthr[rb] : x.c[rb][nb], 0, 0, 0);
+  };
   auto stage_fn = [&](const Acc &cur, Acc &nxt, int key0, int fbuf, int fcb) {
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {  // quarter qd: MFMA step kk = qd of the next block, filter (rb, nb) of this one
       const int rb = qd >> 1, nb = qd & 1;
       const f32x4 &cv = cur.c[rb][nb];
-      mma_step(nxt, qd);
+      // The wave issues in order, so its VALU/LDS instructions only run under its own MFMAs if they sit
+      // BETWEEN them: one 4-pass MFMA leaves a 16-cycle gap = the two or three instructions placed
+      // after it.  Hierarchical reject: max over the 4 accumulator registers (256 scores) + a ballot
+      // (plain fmaxf: an inline-asm v_max3 would bypass hipcc's MFMA->VALU hazard tracking).
+      float m01 = 0.f, m23 = 0.f, mq = 0.f;
+      mma1(nxt, 0, 0, qd);
+      if (kDbg != 1) m01 = fmaxf(cv[0], cv[1]);
       __builtin_amdgcn_sched_barrier(0);
-      fetch(qd, fbuf, fcb);
-      // hierarchical reject: one max over the 4 accumulator registers (256 scores) + a ballot
-      // (plain fmaxf: an inline-asm v_max3 reading MFMA results would bypass hipcc's MFMA->VALU
-      // hazard padding and was observed to miss candidates)
+      mma1(nxt, 1, 0, qd);
+      if (kDbg != 1) m23 = fmaxf(cv[2], cv[3]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma1(nxt, 0, 1, qd);
+      bv[0][qd] = kb[qd][(fbuf * kBN + fcb * 32) * 16];
+      if (kDbg != 1) mq = fmaxf(m01, m23);
+      __builtin_amdgcn_sched_barrier(0);
+      mma1(nxt, 1, 1, qd);
+      bv[1][qd] = kb[qd][(fbuf * kBN + fcb * 32 + 16) * 16];
+      __builtin_amdgcn_sched_barrier(0);
       if (kDbg == 1) {
         if (qd == 0) asm volatile("" ::"v"(cur.c[0][0]), "v"(cur.c[0][1]), "v"(cur.c[1][0]), "v"(cur.c[1][1]));
         continue;
       }
-      const float mq = fmaxf(fmaxf(fmaxf(cv[0], cv[1]), cv[2]), cv[3]);
-      __builtin_amdgcn_sched_barrier(0);
       if (__ballot(mq >= 0.f)) {
         const int key = key0 + 16 * nb + c16;
 #pragma unroll
@@ -302,6 +317,8 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) fetch(kk, 0, 1);
 
+  unsigned long long dbg_store = 0, dbg_barrier = 0, dbg_t0 = 0;
+  if (kDbg == 4) dbg_t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < nt; ++it) {
     const int buf = it & 1;
     const int key0 = (a.tile0 + it) * kBN;
@@ -309,12 +326,30 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
     stage_fn(acc1, acc0, key0 + 32, buf, 3);  // filter block 1 | MFMA block 2 | fetch block 3
     // The other LDS buffer was last read (fetched) before the previous barrier: refill it with the
     // next tile now, so that the fetches of the next two stages can cross the tile boundary.
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if (kDbg == 4) ts0 = __builtin_amdgcn_s_memtime();
     if (it + 1 < nt) store_tile(buf ^ 1);
+    if (kDbg == 4) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ts1 = __builtin_amdgcn_s_memtime();
+    }
     __syncthreads();
+    if (kDbg == 4) {
+      ts2 = __builtin_amdgcn_s_memtime();
+      dbg_store += ts1 - ts0;
+      dbg_barrier += ts2 - ts1;
+    }
     if (it + 2 < nt) load_tile(a.tile0 + it + 2);  // global loads in flight for a whole tile
     // on the last tile the "next tile" blocks are stale LDS: computed and thrown away
     stage_fn(acc0, acc1, key0 + 64, buf ^ 1, 0);  // filter block 2 | MFMA block 3 | fetch next tile's block 0
     stage_fn(acc1, acc0, key0 + 96, buf ^ 1, 1);  // filter block 3 | MFMA next block 0 | fetch next block 1
+  }
+  if (kDbg == 4 && lane == 0) {  // in-kernel stamps (diagnostic build only): cycles per wave
+    unsigned long long *d = a.dbg + 4 * (size_t)(blockIdx.x * 4 + w);
+    d[0] = __builtin_amdgcn_s_memtime() - dbg_t0;
+    d[1] = dbg_store;
+    d[2] = dbg_barrier;
+    d[3] = (unsigned long long)nt;
   }
   if (kDbg != 1 && c16 == 0) {
 #pragma unroll
@@ -535,6 +570,12 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
     ca.dbg = (unsigned long long *)p;  // the 256 spare bytes at the end of the workspace
     (void)hipMemsetAsync(p, 0, 16, s);
   }
+  unsigned long long *stamps = nullptr;
+  const size_t n_waves = (size_t)((nq + kBM - 1) / kBM) * 4;
+  if (mode == 4) {  // diagnostic build with in-kernel stamps
+    ANIREC_HIP_CHECK(hipMalloc((void **)&stamps, n_waves * 32));
+    ca.dbg = stamps;
+  }
   // Super-steps of the key stream: thresholds are fixed inside a launch and refreshed between
   // launches; each super-step doubles the number of keys seen, so a row gains about k_eff new
   // candidates per super-step (the first one, with no threshold yet, must fit the buffer).
@@ -552,6 +593,8 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
 
     else if (mode == 2)
       hipLaunchKernelGGL(k_cand<2>, grid, dim3(256), 0, s, ca);
+    else if (mode == 4)
+      hipLaunchKernelGGL(k_cand<4>, grid, dim3(256), 0, s, ca);
     else
       hipLaunchKernelGGL(k_cand<0>, grid, dim3(256), 0, s, ca);
     if (t1 < ntiles) hipLaunchKernelGGL(k_refresh, dim3(nq), dim3(64), 0, s, ca);
@@ -567,6 +610,22 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
     (void)hipStreamSynchronize(s);
     fprintf(stderr, "[anirec topk debug] nq=%d n=%d appends/row=%.1f super-steps=%d\n", nq, n,
             (double)hv[0] / nq, n_launch);
+  }
+  if (mode == 4) {  // stamps of the LAST super-step
+    std::vector<unsigned long long> hv(n_waves * 4);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(hv.data(), stamps, n_waves * 32, hipMemcpyDeviceToHost);
+    (void)hipFree(stamps);
+    double tot = 0, st = 0, br = 0;
+    for (size_t i = 0; i < n_waves; ++i) {
+      tot += (double)hv[4 * i];
+      st += (double)hv[4 * i + 1];
+      br += (double)hv[4 * i + 2];
+    }
+    const double ntl = (double)hv[3];
+    fprintf(stderr, "[anirec topk stamps] last super-step: %d tiles; per wave per tile: total %.0f cycles, "
+            "vmcnt wait + ds_write %.0f, barrier %.0f\n", (int)ntl, tot / n_waves / ntl, st / n_waves / ntl,
+            br / n_waves / ntl);
   }
   RerankArgs ra;
   ra.What = What;
