@@ -185,27 +185,34 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
       qa[rb][kk] = __builtin_bit_cast(f16x8, v);
     }
   }
-  // Key tiles: Wb is padded with NaN rows to whole tiles (see the host code), so the tile loads need
-  // no bounds test: a wave-uniform base plus eight fixed per-thread offsets.
-  u32x4 stage[8];
-  const uint32_t voff = (uint32_t)tid * 16u;
-  auto load_tile = [&](int t) {
+  // Key tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write).
+  // One instruction moves 64 lanes x 16 B to 1 KiB of LDS starting at M0 = 4 key rows, lane-linear; the
+  // XOR swizzle of the LDS image (slot = chunk ^ (row & 15), conflict-free ds_read_b128) is therefore
+  // applied to the per-lane SOURCE chunk.  Wb is padded with NaN rows to whole tiles (host code), so
+  // there is no bounds test.  Inline asm: the compiler must not order every LDS read behind the DMA
+  // (it would wait vmcnt(0) before each ds_read); the waits are placed by hand next to the barriers.
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  uint32_t doff[8];  // byte offset of this lane's source chunk inside a tile, per DMA instruction
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = 32 * w + 4 * i + (lane >> 4);
+    doff[i] = (uint32_t)((r * 16 + ((lane & 15) ^ (r & 15))) * 16);
+  }
+  const uint32_t ks_base =
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&Ks[0][0] + (uint32_t)wu * 8192u;
+  auto dma_tile = [&](int t, int buf) {
     const char *base = reinterpret_cast<const char *>(a.Wb) + (size_t)t * (kBN * 256);
+    const uint32_t l0 = ks_base + (uint32_t)buf * (kBN * 256);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) stage[i] = *reinterpret_cast<const u32x4 *>(base + (voff + 4096u * i));
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = tid + 256 * i;  // chunk id: key = c >> 4, chunk = c & 15
-      const int key = c >> 4, ch = c & 15;
-      *reinterpret_cast<u32x4 *>(&Ks[buf][key * 16 + (ch ^ (key & 15))]) = stage[i];
-    }
+    for (int i = 0; i < 8; ++i)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                   :
+                   : "v"(doff[i]), "s"(base), "s"(l0 + 1024u * i)
+                   : "memory", "m0");
   };
   const int nt = a.tile1 - a.tile0;
-  load_tile(a.tile0);
-  store_tile(0);
-  if (nt > 1) load_tile(a.tile0 + 1);
+  dma_tile(a.tile0, 0);
+  if (nt > 1) dma_tile(a.tile0 + 1, 1);
 
   // Accumulator register i of block (rb, nb) belongs to query row 16 rb + 4 gq + i of the wave's 32
   // rows: the rows are private to the wave, so their thresholds and buffer counts live in registers
@@ -239,6 +246,7 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
   for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
     for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(cntr[rb][i]), "v"(nthr[rb][i]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // both DMA tiles have landed
   __syncthreads();
 
   // Software pipeline over 32x32 blocks (4 per key tile).  Stage j filters block j while the matrix
@@ -324,11 +332,11 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
     const int key0 = (a.tile0 + it) * kBN;
     stage_fn(acc0, acc1, key0, buf, 2);       // filter block 0 | MFMA block 1 | fetch block 2
     stage_fn(acc1, acc0, key0 + 32, buf, 3);  // filter block 1 | MFMA block 2 | fetch block 3
-    // The other LDS buffer was last read (fetched) before the previous barrier: refill it with the
-    // next tile now, so that the fetches of the next two stages can cross the tile boundary.
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
     if (kDbg == 4) ts0 = __builtin_amdgcn_s_memtime();
-    if (it + 1 < nt) store_tile(buf ^ 1);
+    // tile it+1 was sent to the other buffer one tile ago; its DMA (and this wave's candidate stores,
+    // vmcnt counts in order) must have landed before anyone reads it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (kDbg == 4) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       ts1 = __builtin_amdgcn_s_memtime();
@@ -339,7 +347,9 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
       dbg_store += ts1 - ts0;
       dbg_barrier += ts2 - ts1;
     }
-    if (it + 2 < nt) load_tile(a.tile0 + it + 2);  // global loads in flight for a whole tile
+    // this tile's buffer was last read (fetched) before the barrier: refill it with tile it+2, in
+    // flight for a whole tile
+    if (it + 2 < nt) dma_tile(a.tile0 + it + 2, buf);
     // on the last tile the "next tile" blocks are stale LDS: computed and thrown away
     stage_fn(acc0, acc1, key0 + 64, buf ^ 1, 0);  // filter block 2 | MFMA block 3 | fetch next tile's block 0
     stage_fn(acc1, acc0, key0 + 96, buf ^ 1, 1);  // filter block 3 | MFMA next block 0 | fetch next block 1
@@ -624,7 +634,7 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
     }
     const double ntl = (double)hv[3];
     fprintf(stderr, "[anirec topk stamps] last super-step: %d tiles; per wave per tile: total %.0f cycles, "
-            "vmcnt wait + ds_write %.0f, barrier %.0f\n", (int)ntl, tot / n_waves / ntl, st / n_waves / ntl,
+            "vmcnt wait %.0f, barrier %.0f\n", (int)ntl, tot / n_waves / ntl, st / n_waves / ntl,
             br / n_waves / ntl);
   }
   RerankArgs ra;
