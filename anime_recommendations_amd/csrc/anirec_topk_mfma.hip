@@ -277,18 +277,19 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
       const f32x4 &cv = cur.c[rb][nb];
       // The wave issues in order, so its VALU/LDS instructions only run under its own MFMAs if they sit
       // BETWEEN them: one 4-pass MFMA leaves a 16-cycle gap = the two or three instructions placed
-      // after it.  Hierarchical reject: max over the 4 accumulator registers (256 scores) + a ballot
-      // (plain fmaxf: an inline-asm v_max3 would bypass hipcc's MFMA->VALU hazard tracking).
-      float m01 = 0.f, m23 = 0.f, mq = 0.f;
+      // after it.  Hierarchical reject: max over the 4 accumulator registers (256 scores) + a ballot.
+      // v_max3 by hand: fmaxf() costs two extra canonicalising v_max per quarter.  `cv` was completed a
+      // whole stage (16 MFMAs) ago, far beyond the MFMA->VALU hazard window the compiler would pad;
+      // NaN scores (masked / padding keys) are quiet NaNs, which v_max3 ignores like fmaxf.
+      float m3 = 0.f, mq = 0.f;
       mma1(nxt, 0, 0, qd);
-      if (kDbg != 1) m01 = fmaxf(cv[0], cv[1]);
+      if (kDbg != 1) asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(m3) : "v"(cv[0]), "v"(cv[1]), "v"(cv[2]));
       __builtin_amdgcn_sched_barrier(0);
       mma1(nxt, 1, 0, qd);
-      if (kDbg != 1) m23 = fmaxf(cv[2], cv[3]);
+      if (kDbg != 1) asm volatile("v_max_f32 %0, %1, %2" : "=v"(mq) : "v"(m3), "v"(cv[3]));
       __builtin_amdgcn_sched_barrier(0);
       mma1(nxt, 0, 1, qd);
       bv[0][qd] = kb[qd][(fbuf * kBN + fcb * 32) * 16];
-      if (kDbg != 1) mq = fmaxf(m01, m23);
       __builtin_amdgcn_sched_barrier(0);
       mma1(nxt, 1, 1, qd);
       bv[1][qd] = kb[qd][(fbuf * kBN + fcb * 32 + 16) * 16];
