@@ -35,7 +35,7 @@
 
 namespace anirec {
 
-constexpr int kBM = 128;        // query rows per workgroup (4 waves x 32 rows)
+// query rows per workgroup: 32 per wave x kWaves (4 or 8) waves, template parameter of k_cand
 constexpr int kBN = 128;        // keys per tile
 constexpr int kCap = 512;       // candidate buffer entries per query row
 // |fp16-operand MFMA score - fp32 fma-chain score| for unit-norm rows: each operand is rounded with
@@ -163,8 +163,12 @@ __global__ __launch_bounds__(64) void k_refresh(CandArgs a) {
 // k_cand: one super-step.  128 query rows per workgroup (4 waves x 32 rows, fragments in registers),
 // key tiles of 128 rows double-buffered in XOR-swizzled LDS, thresholds FIXED for the launch.
 // ------------------------------------------------------------------------------------
-template <int kDbg>  // 0: product; 1: no filter (timing experiments only); 2: count appends
-__global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
+// kWaves = 8 (256 query rows per workgroup, one workgroup per CU) halves the L2 -> LDS key traffic per
+// MFMA and is used when the queries fill the chip that way; kWaves = 4 (two workgroups per CU) otherwise.
+template <int kDbg, int kWaves>  // kDbg 0: product; 1: no filter (timing experiments only); 2: count appends; 4: stamps
+__global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
+  constexpr int kBM = 32 * kWaves;
+  constexpr int kDma = 32 / kWaves;  // LDS-DMA instructions per wave per key tile (4 key rows each)
   __shared__ __attribute__((aligned(16))) uint4 Ks[2][kBN * 16];  // 2 x 32 KB
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c16 = lane & 15, gq = lane >> 4;
@@ -192,19 +196,19 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
   // there is no bounds test.  Inline asm: the compiler must not order every LDS read behind the DMA
   // (it would wait vmcnt(0) before each ds_read); the waits are placed by hand next to the barriers.
   const int wu = __builtin_amdgcn_readfirstlane(w);
-  uint32_t doff[8];  // byte offset of this lane's source chunk inside a tile, per DMA instruction
+  uint32_t doff[kDma];  // byte offset of this lane's source chunk inside a tile, per DMA instruction
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int r = 32 * w + 4 * i + (lane >> 4);
+  for (int i = 0; i < kDma; ++i) {
+    const int r = 4 * kDma * w + 4 * i + (lane >> 4);
     doff[i] = (uint32_t)((r * 16 + ((lane & 15) ^ (r & 15))) * 16);
   }
   const uint32_t ks_base =
-      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&Ks[0][0] + (uint32_t)wu * 8192u;
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&Ks[0][0] + (uint32_t)wu * (1024u * kDma);
   auto dma_tile = [&](int t, int buf) {
     const char *base = reinterpret_cast<const char *>(a.Wb) + (size_t)t * (kBN * 256);
     const uint32_t l0 = ks_base + (uint32_t)buf * (kBN * 256);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < kDma; ++i)
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                    :
                    : "v"(doff[i]), "s"(base), "s"(l0 + 1024u * i)
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void k_cand(CandArgs a) {
     stage_fn(acc1, acc0, key0 + 96, buf ^ 1, 1);  // filter block 3 | MFMA next block 0 | fetch next block 1
   }
   if (kDbg == 4 && lane == 0) {  // in-kernel stamps (diagnostic build only): cycles per wave
-    unsigned long long *d = a.dbg + 4 * (size_t)(blockIdx.x * 4 + w);
+    unsigned long long *d = a.dbg + 4 * (size_t)(blockIdx.x * kWaves + w);
     d[0] = __builtin_amdgcn_s_memtime() - dbg_t0;
     d[1] = dbg_store;
     d[2] = dbg_barrier;
@@ -523,7 +527,19 @@ __global__ void k_count_flags(const int32_t *flags, int nq, int32_t *count) {
 
 using namespace anirec;
 
+// HIP-event timing of the MFMA kernel (bench.py's roofline leg): armed by anirec_topk_mfma_timing(1, ...)
+static bool g_time_cand = false;
+static float g_cand_ms = 0.f;     // sum of the k_cand launch durations of the last call
+static int g_cand_launches = 0;
+
 extern "C" {
+
+int anirec_topk_mfma_timing(int32_t enable, float *cand_ms, int32_t *launches) {
+  if (cand_ms) *cand_ms = g_cand_ms;
+  if (launches) *launches = g_cand_launches;
+  g_time_cand = enable != 0;
+  return ANIREC_OK;
+}
 
 // Wb holds whole key tiles: rows n .. padded_keys(n)-1 are NaN rows (never candidates)
 static inline size_t padded_keys(int32_t n) { return ((size_t)n + kBN - 1) / kBN * kBN; }
@@ -582,7 +598,7 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
     (void)hipMemsetAsync(p, 0, 16, s);
   }
   unsigned long long *stamps = nullptr;
-  const size_t n_waves = (size_t)((nq + kBM - 1) / kBM) * 4;
+  const size_t n_waves = ((size_t)nq + 255) / 256 * 8;
   if (mode == 4) {  // diagnostic build with in-kernel stamps
     ANIREC_HIP_CHECK(hipMalloc((void **)&stamps, n_waves * 32));
     ca.dbg = stamps;
@@ -591,29 +607,64 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
   // launches; each super-step doubles the number of keys seen, so a row gains about k_eff new
   // candidates per super-step (the first one, with no threshold yet, must fit the buffer).
   const int ntiles = (n + kBN - 1) / kBN;
-  const dim3 grid((nq + kBM - 1) / kBM);
+  // 256-row workgroups once they give every CU one (8 waves per CU either way); 128-row otherwise
+  const char *wv = getenv("ANIREC_TOPK_WAVES");
+  const bool wide = wv ? atoi(wv) == 8 : nq >= 49152;
+  const dim3 grid(wide ? (nq + 255) / 256 : (nq + 127) / 128);
+  const dim3 block(wide ? 512 : 256);
   int n_launch = 0;
+  std::vector<hipEvent_t> timed;  // event pairs around the k_cand launches (timing mode only)
   const char *gp = getenv("ANIREC_TOPK_GROWTH");
   const int growth_pct = gp ? atoi(gp) : 100;
   for (int t0 = 0, step = (kCap - kBN) / kBN; t0 < ntiles;) {
     const int t1 = t0 + step < ntiles ? t0 + step : ntiles;
     ca.tile0 = t0;
     ca.tile1 = t1;
+#define ANIREC_LAUNCH_CAND(D)                                              \
+  do {                                                                     \
+    if (wide)                                                              \
+      hipLaunchKernelGGL((k_cand<D, 8>), grid, block, 0, s, ca);           \
+    else                                                                   \
+      hipLaunchKernelGGL((k_cand<D, 4>), grid, block, 0, s, ca);           \
+  } while (0)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (g_time_cand) {
+      ANIREC_HIP_CHECK(hipEventCreate(&ev0));
+      ANIREC_HIP_CHECK(hipEventCreate(&ev1));
+      ANIREC_HIP_CHECK(hipEventRecord(ev0, s));
+    }
     if (mode == 1)
-      hipLaunchKernelGGL(k_cand<1>, grid, dim3(256), 0, s, ca);
-
+      ANIREC_LAUNCH_CAND(1);
     else if (mode == 2)
-      hipLaunchKernelGGL(k_cand<2>, grid, dim3(256), 0, s, ca);
+      ANIREC_LAUNCH_CAND(2);
     else if (mode == 4)
-      hipLaunchKernelGGL(k_cand<4>, grid, dim3(256), 0, s, ca);
+      ANIREC_LAUNCH_CAND(4);
     else
-      hipLaunchKernelGGL(k_cand<0>, grid, dim3(256), 0, s, ca);
+      ANIREC_LAUNCH_CAND(0);
+#undef ANIREC_LAUNCH_CAND
+    if (g_time_cand) {
+      ANIREC_HIP_CHECK(hipEventRecord(ev1, s));
+      timed.push_back(ev0);
+      timed.push_back(ev1);
+    }
     if (t1 < ntiles) hipLaunchKernelGGL(k_refresh, dim3(nq), dim3(64), 0, s, ca);
     ANIREC_HIP_CHECK(hipGetLastError());
     step = (int)((long long)t1 * growth_pct / 100);  // next super-step: growth_pct % of the tiles seen so far
     if (step < 1) step = 1;
     t0 = t1;
     ++n_launch;
+  }
+  if (g_time_cand) {  // blocking: only bench.py's roofline leg arms this
+    g_cand_ms = 0.f;
+    g_cand_launches = (int)timed.size() / 2;
+    for (size_t i = 0; i + 1 < timed.size(); i += 2) {
+      float ms = 0.f;
+      (void)hipEventSynchronize(timed[i + 1]);
+      (void)hipEventElapsedTime(&ms, timed[i], timed[i + 1]);
+      g_cand_ms += ms;
+      (void)hipEventDestroy(timed[i]);
+      (void)hipEventDestroy(timed[i + 1]);
+    }
   }
   if (mode == 2) {
     unsigned long long hv[2] = {0, 0};

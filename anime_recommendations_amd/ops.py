@@ -89,7 +89,7 @@ def cosine_topk(What, queries, k, exclude_self=True, keep=None, workspace=None):
 
 
 def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=65536, fallback=True):
-    """cosine_topk on the matrix cores (bf16 MFMA candidates + exact fp32 re-rank); rows the
+    """cosine_topk on the matrix cores (fp16 MFMA candidates + exact fp32 re-rank); rows the
     kernel could not prove complete are transparently re-run through the exact kernels.
     Returns (idx, score, n_fallback)."""
     _need_gpu()
@@ -124,6 +124,15 @@ def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=65536
             out_i[q0 + bad] = fi
             out_s[q0 + bad] = fs
     return out_i, out_s, n_fb
+
+
+def topk_mfma_timing(enable):
+    """Arm / disarm HIP-event timing of the MFMA candidate kernel; returns (ms, launches) of the last
+    armed cosine_topk_mfma call (bench.py's roofline leg)."""
+    lib = _lib.load()
+    ms, nl = C.c_float(0.0), C.c_int32(0)
+    _lib.check(lib.anirec_topk_mfma_timing(int(bool(enable)), C.byref(ms), C.byref(nl)), "anirec_topk_mfma_timing")
+    return float(ms.value), int(nl.value)
 
 
 def _head_struct(head):

@@ -206,7 +206,7 @@ int anirec_cosine_topk(const float *What, int32_t n, const int32_t *queries, int
                        const uint8_t *keep, int32_t exclude_self, int32_t k, int32_t *out_idx,
                        float *out_score, void *workspace, size_t workspace_bytes, void *stream);
 
-/* Same result as anirec_cosine_topk on the matrix cores: bf16 MFMA candidate scores for all
+/* Same result as anirec_cosine_topk on the matrix cores: fp16 MFMA candidate scores for all
  * keys with a rigorous error window, exact fp32 fma-chain re-rank of the survivors.
  * flags[nq] (device) is non-zero for the rare query whose window could not be proven
  * complete (dense ties / more than 256 survivors); its output row is -1/NaN and the caller
@@ -216,6 +216,10 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
                             const uint8_t *keep, int32_t exclude_self, int32_t k, int32_t *out_idx,
                             float *out_score, int32_t *flags, void *workspace,
                             size_t workspace_bytes, void *stream);
+/* Measurement hook (bench.py's roofline leg): returns the summed HIP-event duration [ms] and the
+ * number of the MFMA candidate-kernel launches of the LAST anirec_cosine_topk_mfma call made while
+ * armed, then arms (enable != 0) or disarms the timing.  Armed calls block until the stream drains. */
+int anirec_topk_mfma_timing(int32_t enable, float *cand_ms, int32_t *launches);
 
 /* ------------------------------------------------------------------------- *
  *  PREDICTION — replaces model.predict([user_arr, anime_arr]), model_recs/model_recs.py:394
