@@ -66,7 +66,12 @@ class Head(C.Structure):
                 ("mov_mean", C.c_float), ("mov_var", C.c_float)]
 
 
-_vp, _i32, _sz, _f32 = C.c_void_p, C.c_int32, C.c_size_t, C.c_float
+class IngestOpts(C.Structure):
+    _fields_ = [("num_reviews", C.c_int32), ("drop_unwatched", C.c_int32), ("drop_plan", C.c_int32),
+                ("drop_half_watched", C.c_int32), ("user_id_bound", C.c_int32), ("anime_id_bound", C.c_int32)]
+
+
+_vp, _i32, _sz, _f32, _i64 = C.c_void_p, C.c_int32, C.c_size_t, C.c_float, C.c_int64
 _DP = C.POINTER(TrainDesc)
 
 # name -> (restype, argtypes); must list every function include/anirec.h declares
@@ -103,6 +108,11 @@ PROTOTYPES = {
     "anirec_predict_grid_mfma": (C.c_int, [_vp, _vp, _i32, _vp, _i32, C.POINTER(Head), _vp, _vp, _sz, _vp]),
     "anirec_predict_topk": (C.c_int, [_vp, _vp, _i32, _vp, _i32, C.POINTER(Head), _vp, _i32, _vp,
                                       _vp, _vp, _sz, _vp]),
+    "anirec_ingest_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "anirec_ingest_preprocess": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(IngestOpts), _vp, _vp, _vp,
+                                           _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "anirec_ingest_encode_workspace_bytes": (_sz, [_i64, _i32]),
+    "anirec_ingest_encode": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -13,7 +13,8 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libanirec.so")
-SOURCES = ["anirec_misc.hip", "anirec_train.hip", "anirec_infer.hip", "anirec_topk_mfma.hip", "anirec_predict_mfma.hip"]
+SOURCES = ["anirec_misc.hip", "anirec_train.hip", "anirec_infer.hip", "anirec_topk_mfma.hip", "anirec_predict_mfma.hip",
+           "anirec_ingest.hip"]
 
 
 def hipcc_path() -> str:

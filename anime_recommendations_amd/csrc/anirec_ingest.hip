@@ -1,0 +1,420 @@
+// Rating-table ingest on the GPU: the step immediately before the hot path.
+//
+// Replaces, for columns already resident in HBM,
+//   preprocess/preprocess.py:13-40   drop_useless   (drop_duplicates, dropna, watched/plan filters,
+//                                                    users with fewer than num_reviews ratings)
+//   preprocess/preprocess.py:52-105  drop_half_watched (per-anime max episodes, keep >= half)
+//   preprocess/preprocess.py:108-117 scale_ratings  ((x - min) / (max - min), float64)
+//   neural_network/neural_network.py:41-60 get_df   (id -> position in Series.unique(): order of
+//                                                    first appearance)
+// which the reference does with pandas (dict lookups and Python loops per row).  All of it is
+// HBM-bound integer / byte work: flag passes, one open-addressing hash table for the duplicate rows,
+// direct-index tables for the per-user / per-anime aggregates, and a 3-pass flag scan that turns
+// flags into stable (order-preserving) output positions.  Results are bit-identical to pandas:
+// the surviving rows keep their order, duplicates keep their FIRST occurrence, indices follow first
+// appearance, and the scaling is the same IEEE double expression.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "anirec_dev.hpp"
+
+namespace anirec {
+
+constexpr int kScanTile = 4096;  // flags per workgroup of the scan (256 threads x 16 flags)
+
+struct IngestCols {
+  const int32_t *user, *anime;
+  const double *rating;
+  const int32_t *status, *episodes;
+};
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+// pandas hashes / compares 0.0 and -0.0 as equal; NaN rows never reach the table
+__device__ __forceinline__ uint64_t rating_bits(double r) { return (uint64_t)__double_as_longlong(r + 0.0); }
+
+__device__ __forceinline__ uint64_t row_hash(const IngestCols &c, int64_t i) {
+  uint64_t h = mix64(((uint64_t)(uint32_t)c.user[i] << 32) | (uint32_t)c.anime[i]);
+  h = mix64(h ^ rating_bits(c.rating[i]));
+  h = mix64(h ^ (((uint64_t)(uint32_t)c.status[i] << 32) | (uint32_t)c.episodes[i]));
+  return h;
+}
+__device__ __forceinline__ bool row_eq(const IngestCols &c, int64_t i, int64_t j) {
+  return c.user[i] == c.user[j] && c.anime[i] == c.anime[j] && c.status[i] == c.status[j] &&
+         c.episodes[i] == c.episodes[j] && rating_bits(c.rating[i]) == rating_bits(c.rating[j]);
+}
+
+// dropna + the two row-local filters (they commute with drop_duplicates: duplicates share their fate)
+__global__ __launch_bounds__(256) void k_ing_alive(IngestCols c, int64_t n, int drop_unwatched, int drop_plan,
+                                                   int user_bound, int anime_bound, uint8_t *alive,
+                                                   int32_t *err) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int32_t u = c.user[i], a = c.anime[i], s = c.status[i], e = c.episodes[i];
+    const double r = c.rating[i];
+    bool ok = u != ANIREC_NULL_I32 && a != ANIREC_NULL_I32 && s != ANIREC_NULL_I32 && e != ANIREC_NULL_I32 &&
+              r == r;
+    if (ok && (u < 0 || u >= user_bound || a < 0 || a >= anime_bound)) {
+      *err = 1;  // id outside the direct-index tables: the host reports ANIREC_EINVAL
+      ok = false;
+    }
+    if (ok && drop_unwatched && e == 0) ok = false;
+    if (ok && drop_plan && s == 6) ok = false;
+    alive[i] = ok ? 1 : 0;
+  }
+}
+
+// drop_duplicates(keep='first'): every class of identical rows owns one table slot holding the
+// SMALLEST row index of the class (atomicMin), whatever the insertion order
+__global__ __launch_bounds__(256) void k_ing_insert(IngestCols c, int64_t n, const uint8_t *alive, int32_t *table,
+                                                    uint32_t mask) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (!alive[i]) continue;
+    uint32_t s = (uint32_t)row_hash(c, i) & mask;
+    for (;;) {
+      const int32_t old = atomicCAS(&table[s], -1, (int32_t)i);
+      if (old == -1) break;
+      if (row_eq(c, i, old)) {
+        atomicMin(&table[s], (int32_t)i);
+        break;
+      }
+      s = (s + 1) & mask;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_ing_mark(const int32_t *table, uint32_t slots, uint8_t *keep) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < slots; s += stride) {
+    const int32_t j = table[s];
+    if (j >= 0) keep[j] = 1;
+  }
+}
+
+// value_counts() of user_id over the surviving rows, then the num_reviews filter
+__global__ __launch_bounds__(256) void k_ing_count(const int32_t *id, int64_t n, const uint8_t *keep, int32_t *cnt) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    if (keep[i]) atomicAdd(&cnt[id[i]], 1);
+}
+__global__ __launch_bounds__(256) void k_ing_user_filter(const int32_t *user, int64_t n, const int32_t *cnt,
+                                                         int num_reviews, uint8_t *keep) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    if (keep[i] && cnt[user[i]] < num_reviews) keep[i] = 0;
+}
+// groupby('anime_id')['watched_episodes'].max(), then keep watched >= (max == 1 ? 1 : max * .5)
+__global__ __launch_bounds__(256) void k_ing_anime_max(IngestCols c, int64_t n, const uint8_t *keep, int32_t *mx) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    if (keep[i]) atomicMax(&mx[c.anime[i]], c.episodes[i]);
+}
+__global__ __launch_bounds__(256) void k_ing_half_filter(IngestCols c, int64_t n, const int32_t *mx, uint8_t *keep) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (!keep[i]) continue;
+    const int32_t m = mx[c.anime[i]];
+    const double half = m == 1 ? 1.0 : (double)m * .5;
+    if (!((double)c.episodes[i] >= half)) keep[i] = 0;
+  }
+}
+
+// order-preserving double <-> uint64 (for atomicMin / atomicMax)
+__device__ __forceinline__ unsigned long long d2ord(double d) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+__host__ __device__ inline double ord2d(unsigned long long o) {
+  const unsigned long long b = (o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFULL) : ~o;
+  double d;
+  memcpy(&d, &b, 8);
+  return d;
+}
+// min(df['rating']), max(df['rating']) over the surviving rows
+__global__ __launch_bounds__(256) void k_ing_minmax(const double *rating, int64_t n, const uint8_t *keep,
+                                                    unsigned long long *mm) {
+  unsigned long long lo = ~0ULL, hi = 0ULL;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (!keep[i]) continue;
+    const unsigned long long o = d2ord(rating[i]);
+    lo = o < lo ? o : lo;
+    hi = o > hi ? o : hi;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned long long l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if (lane_id() == 0) {
+    atomicMin(&mm[0], lo);
+    atomicMax(&mm[1], hi);
+  }
+}
+
+// ---- exclusive scan of byte flags -> int32 positions (3 passes; flags padded with zeros to a tile) ----
+__global__ __launch_bounds__(256) void k_scan_reduce(const uint8_t *flags, int32_t *bsum) {
+  __shared__ int wsum[4];
+  const uint4 v = reinterpret_cast<const uint4 *>(flags)[(size_t)blockIdx.x * 256 + threadIdx.x];
+  // flags are 0/1 bytes: the byte sum of a dword is a popcount
+  int s = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane_id() == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) bsum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(1024) void k_scan_spine(int32_t *bsum, int nb, int64_t *total) {
+  __shared__ long long part[1024];
+  const int per = (nb + 1023) / 1024;
+  const int b0 = threadIdx.x * per, b1 = min(nb, b0 + per);
+  long long s = 0;
+  for (int b = b0; b < b1; ++b) s += bsum[b];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long run = 0;
+    for (int t = 0; t < 1024; ++t) {
+      const long long x = part[t];
+      part[t] = run;
+      run += x;
+    }
+    *total = run;
+  }
+  __syncthreads();
+  int run = (int)part[threadIdx.x];
+  for (int b = b0; b < b1; ++b) {
+    const int x = bsum[b];
+    bsum[b] = run;
+    run += x;
+  }
+}
+__global__ __launch_bounds__(256) void k_scan_apply(const uint8_t *flags, const int32_t *bsum, int32_t *pos) {
+  __shared__ int wsum[4];
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const uint4 v = reinterpret_cast<const uint4 *>(flags)[t];
+  const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+  const int mine = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+  int incl = mine;  // inclusive scan over the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(incl, o, 64);
+    if (lane_id() >= o) incl += y;
+  }
+  if (lane_id() == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  int base = bsum[blockIdx.x];
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wsum[w];
+  int run = base + incl - mine;
+  int32_t out[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    out[j] = run;
+    run += (wds[j >> 2] >> (8 * (j & 3))) & 1u;
+  }
+  int4 *dst = reinterpret_cast<int4 *>(pos + t * 16);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dst[j] = make_int4(out[4 * j], out[4 * j + 1], out[4 * j + 2], out[4 * j + 3]);
+}
+
+struct IngestOut {
+  int32_t *user, *anime;
+  double *rating;
+  int32_t *status, *episodes;
+};
+// stable compaction + scale_ratings
+__global__ __launch_bounds__(256) void k_ing_compact(IngestCols c, int64_t n, const uint8_t *keep, const int32_t *pos,
+                                                     const unsigned long long *mm, IngestOut o) {
+  const double mn = ord2d(mm[0]), mx = ord2d(mm[1]);
+  const double span = mx - mn;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (!keep[i]) continue;
+    const int32_t p = pos[i];
+    o.user[p] = c.user[i];
+    o.anime[p] = c.anime[i];
+    o.rating[p] = (c.rating[i] - mn) / span;
+    o.status[p] = c.status[i];
+    o.episodes[p] = c.episodes[i];
+  }
+}
+
+// ---- Series.unique() encoding: dense index = rank of the id's first appearance ----
+__global__ __launch_bounds__(256) void k_enc_first(const int32_t *id, int64_t n, int bound, int32_t *first, int32_t *err) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int32_t v = id[i];
+    if (v < 0 || v >= bound) {
+      *err = 1;
+      continue;
+    }
+    atomicMin(&first[v], (int32_t)i);
+  }
+}
+__global__ __launch_bounds__(256) void k_enc_flag(const int32_t *id, int64_t n, int bound, const int32_t *first,
+                                                  uint8_t *isfirst) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int32_t v = id[i];
+    isfirst[i] = (v >= 0 && v < bound && first[v] == (int32_t)i) ? 1 : 0;
+  }
+}
+__global__ __launch_bounds__(256) void k_enc_emit(const int32_t *id, int64_t n, int bound, const int32_t *first,
+                                                  const uint8_t *isfirst, const int32_t *rank, int32_t *idx,
+                                                  int32_t *uniques) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int32_t v = id[i];
+    if (v < 0 || v >= bound) {
+      idx[i] = -1;
+      continue;
+    }
+    idx[i] = rank[first[v]];
+    if (isfirst[i]) uniques[rank[i]] = v;
+  }
+}
+
+static inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
+static inline size_t pad_tile(int64_t n) { return ((size_t)n + kScanTile - 1) / kScanTile * kScanTile; }
+static inline uint32_t table_slots(int64_t n) {
+  uint64_t s = 1024;
+  while (s < (uint64_t)n * 2) s <<= 1;
+  return (uint32_t)s;
+}
+static inline int grid_for(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 16384) b = 16384;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+// flags (padded, tail zeroed by the caller) -> pos, total
+static int scan_flags(const uint8_t *flags, int64_t n, int32_t *bsum, int32_t *pos, int64_t *total, hipStream_t s) {
+  const int nb = (int)(pad_tile(n) / kScanTile);
+  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, s, flags, bsum);
+  hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, bsum, nb, total);
+  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, s, flags, bsum, pos);
+  return (int)hipGetLastError();
+}
+
+}  // namespace anirec
+
+using namespace anirec;
+
+extern "C" {
+
+// alive | keep (padded byte flags) | pos | bsum | hash table | user counts | anime max | minmax + err
+size_t anirec_ingest_workspace_bytes(int64_t n, int32_t user_id_bound, int32_t anime_id_bound) {
+  if (n < 1 || n >= ((int64_t)1 << 30) || user_id_bound < 1 || anime_id_bound < 1) return 0;
+  const size_t np = pad_tile(n);
+  return 2 * al256(np) + al256(np * 4) + al256(np / kScanTile * 4) + al256((size_t)table_slots(n) * 4) +
+         al256((size_t)user_id_bound * 4) + al256((size_t)anime_id_bound * 4) + 256;
+}
+
+int anirec_ingest_preprocess(const int32_t *user_id, const int32_t *anime_id, const double *rating,
+                             const int32_t *watching_status, const int32_t *watched_episodes, int64_t n,
+                             const anirec_ingest_opts *opts, int32_t *out_user_id, int32_t *out_anime_id,
+                             double *out_rating, int32_t *out_status, int32_t *out_episodes, int64_t *n_out,
+                             int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!user_id || !anime_id || !rating || !watching_status || !watched_episodes || !opts || !out_user_id ||
+      !out_anime_id || !out_rating || !out_status || !out_episodes || !n_out || !err_flag || !workspace)
+    return ANIREC_EINVAL;
+  if (n < 1 || n >= ((int64_t)1 << 30) || opts->user_id_bound < 1 || opts->anime_id_bound < 1) return ANIREC_EINVAL;
+  if (workspace_bytes < anirec_ingest_workspace_bytes(n, opts->user_id_bound, opts->anime_id_bound))
+    return ANIREC_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t np = pad_tile(n);
+  const uint32_t slots = table_slots(n);
+  char *p = (char *)workspace;
+  uint8_t *alive = (uint8_t *)p;
+  p += al256(np);
+  uint8_t *keep = (uint8_t *)p;
+  p += al256(np);
+  int32_t *pos = (int32_t *)p;
+  p += al256(np * 4);
+  int32_t *bsum = (int32_t *)p;
+  p += al256(np / kScanTile * 4);
+  int32_t *table = (int32_t *)p;
+  p += al256((size_t)slots * 4);
+  int32_t *cnt_u = (int32_t *)p;
+  p += al256((size_t)opts->user_id_bound * 4);
+  int32_t *max_ep = (int32_t *)p;
+  p += al256((size_t)opts->anime_id_bound * 4);
+  unsigned long long *mm = (unsigned long long *)p;
+
+  const IngestCols c{user_id, anime_id, rating, watching_status, watched_episodes};
+  const int g = grid_for(n);
+  ANIREC_HIP_CHECK(hipMemsetAsync(err_flag, 0, 4, s));
+  ANIREC_HIP_CHECK(hipMemsetAsync(keep, 0, np, s));
+  ANIREC_HIP_CHECK(hipMemsetAsync(alive + n, 0, np - (size_t)n, s));
+  ANIREC_HIP_CHECK(hipMemsetAsync(table, 0xFF, (size_t)slots * 4, s));
+  ANIREC_HIP_CHECK(hipMemsetAsync(cnt_u, 0, (size_t)opts->user_id_bound * 4, s));
+  ANIREC_HIP_CHECK(hipMemsetAsync(mm, 0xFF, 8, s));
+  ANIREC_HIP_CHECK(hipMemsetAsync(mm + 1, 0, 8, s));
+  hipLaunchKernelGGL(k_ing_alive, dim3(g), dim3(256), 0, s, c, n, opts->drop_unwatched, opts->drop_plan,
+                     opts->user_id_bound, opts->anime_id_bound, alive, err_flag);
+  hipLaunchKernelGGL(k_ing_insert, dim3(g), dim3(256), 0, s, c, n, alive, table, slots - 1);
+  hipLaunchKernelGGL(k_ing_mark, dim3(grid_for(slots)), dim3(256), 0, s, table, slots, keep);
+  hipLaunchKernelGGL(k_ing_count, dim3(g), dim3(256), 0, s, user_id, n, keep, cnt_u);
+  hipLaunchKernelGGL(k_ing_user_filter, dim3(g), dim3(256), 0, s, user_id, n, cnt_u, opts->num_reviews, keep);
+  if (opts->drop_half_watched) {
+    // episodes can be any int32: start the per-anime maxima at INT32_MIN (0x80 bytes give 0x80808080 < 0,
+    // below every non-null value is not guaranteed, so set exactly)
+    ANIREC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)max_ep, (int)0x80000000, (size_t)opts->anime_id_bound, s));
+    hipLaunchKernelGGL(k_ing_anime_max, dim3(g), dim3(256), 0, s, c, n, keep, max_ep);
+    hipLaunchKernelGGL(k_ing_half_filter, dim3(g), dim3(256), 0, s, c, n, max_ep, keep);
+  }
+  hipLaunchKernelGGL(k_ing_minmax, dim3(g > 2048 ? 2048 : g), dim3(256), 0, s, rating, n, keep, mm);
+  ANIREC_HIP_CHECK(hipGetLastError());
+  int rc = scan_flags(keep, n, bsum, pos, n_out, s);
+  if (rc) return rc;
+  const IngestOut o{out_user_id, out_anime_id, out_rating, out_status, out_episodes};
+  hipLaunchKernelGGL(k_ing_compact, dim3(g), dim3(256), 0, s, c, n, keep, pos, mm, o);
+  return (int)hipGetLastError();
+}
+
+// isfirst (padded) | rank | bsum | first-appearance table
+size_t anirec_ingest_encode_workspace_bytes(int64_t n, int32_t id_bound) {
+  if (n < 1 || n >= ((int64_t)1 << 30) || id_bound < 1) return 0;
+  const size_t np = pad_tile(n);
+  return al256(np) + al256(np * 4) + al256(np / kScanTile * 4) + al256((size_t)id_bound * 4) + 256;
+}
+
+int anirec_ingest_encode(const int32_t *id, int64_t n, int32_t id_bound, int32_t *out_index, int32_t *out_uniques,
+                         int64_t *n_unique, int32_t *err_flag, void *workspace, size_t workspace_bytes,
+                         void *stream) {
+  if (!id || !out_index || !out_uniques || !n_unique || !err_flag || !workspace) return ANIREC_EINVAL;
+  if (n < 1 || n >= ((int64_t)1 << 30) || id_bound < 1) return ANIREC_EINVAL;
+  if (workspace_bytes < anirec_ingest_encode_workspace_bytes(n, id_bound)) return ANIREC_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t np = pad_tile(n);
+  char *p = (char *)workspace;
+  uint8_t *isfirst = (uint8_t *)p;
+  p += al256(np);
+  int32_t *rank = (int32_t *)p;
+  p += al256(np * 4);
+  int32_t *bsum = (int32_t *)p;
+  p += al256(np / kScanTile * 4);
+  int32_t *first = (int32_t *)p;
+  const int g = grid_for(n);
+  ANIREC_HIP_CHECK(hipMemsetAsync(err_flag, 0, 4, s));
+  ANIREC_HIP_CHECK(hipMemsetAsync(isfirst + n, 0, np - (size_t)n, s));
+  ANIREC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)first, 0x7FFFFFFF, (size_t)id_bound, s));
+  hipLaunchKernelGGL(k_enc_first, dim3(g), dim3(256), 0, s, id, n, id_bound, first, err_flag);
+  hipLaunchKernelGGL(k_enc_flag, dim3(g), dim3(256), 0, s, id, n, id_bound, first, isfirst);
+  ANIREC_HIP_CHECK(hipGetLastError());
+  int rc = scan_flags(isfirst, n, bsum, rank, n_unique, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_enc_emit, dim3(g), dim3(256), 0, s, id, n, id_bound, first, isfirst, rank, out_index,
+                     out_uniques);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+"""Rating-table ingest on the GPU — host side of ``anirec_ingest_*``.
+
+Mirrors the reference's preprocess step (preprocess/preprocess.py:13-40 ``drop_useless``, :52-105
+``drop_half_watched``, :108-117 ``scale_ratings``) and the id encoding of ``get_df``
+(neural_network/neural_network.py:41-60).  The columns live in HBM as int32 / float64 tensors; the
+surviving rows keep their order and every value is bit-identical to what pandas produces.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+
+NULL_I32 = -2 ** 31
+COLUMNS = ("user_id", "anime_id", "rating", "watching_status", "watched_episodes")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.AnirecError("no GPU: the anime_recommendations_amd ingest path needs an MI355X")
+
+
+def frame_to_columns(df, device="cuda:0"):
+    """DataFrame (reference schema) -> dict of device tensors.  Integer columns become int32 with
+    missing values (pandas NaN) as NULL_I32; ``rating`` becomes float64 with NaN for missing."""
+    out = {}
+    for name in COLUMNS:
+        col = df[name].to_numpy()
+        if name == "rating":
+            out[name] = torch.as_tensor(np.asarray(col, dtype=np.float64), device=device)
+            continue
+        if col.dtype.kind == "f":
+            bad = ~np.isfinite(col)
+            if np.any(col[~bad] != np.floor(col[~bad])) or np.any(np.abs(col[~bad]) >= 2 ** 31):
+                raise ValueError("column %s holds non-integer values" % name)
+            ints = np.where(bad, NULL_I32, np.where(bad, 0, col)).astype(np.int64)
+        else:
+            ints = col.astype(np.int64)
+            if ints.size and (ints.max() >= 2 ** 31 or ints.min() <= NULL_I32):
+                raise ValueError("column %s does not fit int32" % name)
+        out[name] = torch.as_tensor(ints.astype(np.int32), device=device)
+    return out
+
+
+def _bound(t):
+    """Exclusive upper bound of the non-missing ids of a column (size of its direct-index table)."""
+    return max(int(t.max()) + 1, 1) if t.numel() else 1
+
+
+def preprocess_columns(cols, num_reviews, drop_unwatched=False, drop_plan=False, drop_half_watched=False):
+    """drop_useless (+ drop_half_watched) + scale_ratings on device columns.
+    Returns a dict of device tensors with the surviving rows in their original order."""
+    _need_gpu()
+    lib = _lib.load()
+    u, a = cols["user_id"].contiguous(), cols["anime_id"].contiguous()
+    r = cols["rating"].contiguous()
+    s, e = cols["watching_status"].contiguous(), cols["watched_episodes"].contiguous()
+    assert u.dtype == a.dtype == s.dtype == e.dtype == torch.int32 and r.dtype == torch.float64
+    n = int(u.numel())
+    dev = u.device
+    if n == 0:
+        return {k: cols[k][:0] for k in COLUMNS}
+    opts = _lib.IngestOpts(int(num_reviews), int(bool(drop_unwatched)), int(bool(drop_plan)),
+                           int(bool(drop_half_watched)), _bound(u), _bound(a))
+    ou, oa = torch.empty_like(u), torch.empty_like(a)
+    orr, os_, oe = torch.empty_like(r), torch.empty_like(s), torch.empty_like(e)
+    n_out = torch.zeros(1, dtype=torch.int64, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(int(lib.anirec_ingest_workspace_bytes(n, opts.user_id_bound, opts.anime_id_bound)),
+                     dtype=torch.uint8, device=dev)
+    _lib.check(lib.anirec_ingest_preprocess(_lib.ptr(u), _lib.ptr(a), _lib.ptr(r), _lib.ptr(s), _lib.ptr(e), n,
+                                            C.byref(opts), _lib.ptr(ou), _lib.ptr(oa), _lib.ptr(orr),
+                                            _lib.ptr(os_), _lib.ptr(oe), _lib.ptr(n_out), _lib.ptr(err),
+                                            _lib.ptr(ws), ws.numel(), _stream()), "anirec_ingest_preprocess")
+    m = int(n_out.item())
+    if int(err.item()):
+        raise ValueError("negative user_id / anime_id in the rating table")
+    if m and bool(torch.isnan(orr[0])):
+        # max == min: the reference's scale_ratings raises here too (preprocess.py:115, Python floats)
+        raise ZeroDivisionError("float division by zero (all surviving ratings are equal)")
+    return {"user_id": ou[:m], "anime_id": oa[:m], "rating": orr[:m], "watching_status": os_[:m],
+            "watched_episodes": oe[:m]}
+
+
+def encode_ids(ids):
+    """``Series.unique()`` encoding on the GPU: (index int32 [n], uniques int32 [n_unique])."""
+    _need_gpu()
+    lib = _lib.load()
+    ids = ids.contiguous()
+    assert ids.dtype == torch.int32
+    n = int(ids.numel())
+    dev = ids.device
+    if n == 0:
+        return ids.clone(), ids.clone()
+    bound = _bound(ids)
+    idx = torch.empty_like(ids)
+    uniq = torch.empty(min(n, bound), dtype=torch.int32, device=dev)
+    n_u = torch.zeros(1, dtype=torch.int64, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(int(lib.anirec_ingest_encode_workspace_bytes(n, bound)), dtype=torch.uint8, device=dev)
+    _lib.check(lib.anirec_ingest_encode(_lib.ptr(ids), n, bound, _lib.ptr(idx), _lib.ptr(uniq), _lib.ptr(n_u),
+                                        _lib.ptr(err), _lib.ptr(ws), ws.numel(), _stream()),
+               "anirec_ingest_encode")
+    if int(err.item()):
+        raise ValueError("negative id in the column to encode")
+    return idx, uniq[:int(n_u.item())]
+
+
+@dataclass
+class EncodedRatings:
+    """get_df() on the GPU: encoded (and optionally shuffled) rating columns + the id tables."""
+    user: torch.Tensor       # int32 [N] dense user index
+    anime: torch.Tensor      # int32 [N] dense anime index
+    rating: torch.Tensor     # float64 [N]
+    user_ids: torch.Tensor   # index -> original user_id
+    anime_ids: torch.Tensor  # index -> original anime_id
+
+
+def encode_columns(cols, shuffle=True, random_state=42) -> EncodedRatings:
+    """neural_network.py:41-60: encode both id columns by first appearance, then shuffle the rows
+    with ``df.sample(frac=1, random_state=42)`` (the permutation itself is NumPy's MT19937 stream,
+    generated on the host; the three columns are permuted on the GPU)."""
+    from . import data, ops
+    ui, user_ids = encode_ids(cols["user_id"])
+    ai, anime_ids = encode_ids(cols["anime_id"])
+    r = cols["rating"]
+    if shuffle and ui.numel():
+        perm = torch.as_tensor(data.shuffle_order(int(ui.numel()), random_state), device=ui.device)
+        ui, ai = ui[perm], ai[perm]
+        r = r[perm]
+    return EncodedRatings(ui, ai, r, user_ids, anime_ids)

@@ -259,6 +259,42 @@ int anirec_predict_topk(const float *U, const float *A, int32_t n_anime, const i
                         int32_t k, int32_t *out_idx, float *out_p, void *workspace,
                         size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------- *
+ *  INGEST — the step before the hot path, columns resident in HBM.
+ *  Replaces preprocess/preprocess.py:13-40 (drop_useless: drop_duplicates keep-first, dropna,
+ *  watched/plan filters, users with < num_reviews ratings), :52-105 (drop_half_watched),
+ *  :108-117 (scale_ratings, float64) and the id -> Series.unique() position encoding of
+ *  neural_network/neural_network.py:41-60.  Surviving rows keep their order; results are
+ *  bit-identical to pandas.
+ * ------------------------------------------------------------------------- */
+#define ANIREC_NULL_I32 INT32_MIN /* missing value of an integer column (pandas NaN) */
+
+typedef struct anirec_ingest_opts {
+  int32_t num_reviews;       /* keep users with at least this many surviving ratings */
+  int32_t drop_unwatched;    /* drop rows with watched_episodes == 0 */
+  int32_t drop_plan;         /* drop rows with watching_status == 6 */
+  int32_t drop_half_watched; /* drop rows with watched < half of the anime's max watched */
+  int32_t user_id_bound;     /* ids must lie in [0, bound): sizes of the direct-index tables */
+  int32_t anime_id_bound;
+} anirec_ingest_opts;
+
+/* rating: float64, NaN = missing.  Outputs hold up to n rows; *n_out (device) receives the row
+ * count; *err_flag (device) becomes 1 if a non-missing id is outside its bound (that row is
+ * dropped).  1 <= n < 2^30. */
+size_t anirec_ingest_workspace_bytes(int64_t n, int32_t user_id_bound, int32_t anime_id_bound);
+int anirec_ingest_preprocess(const int32_t *user_id, const int32_t *anime_id, const double *rating,
+                             const int32_t *watching_status, const int32_t *watched_episodes, int64_t n,
+                             const anirec_ingest_opts *opts, int32_t *out_user_id, int32_t *out_anime_id,
+                             double *out_rating, int32_t *out_status, int32_t *out_episodes, int64_t *n_out,
+                             int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream);
+
+/* out_index[i] = position of id[i] in the order of first appearance (pandas Series.unique());
+ * out_uniques[j] = the j-th distinct id; *n_unique (device) = number of distinct ids. */
+size_t anirec_ingest_encode_workspace_bytes(int64_t n, int32_t id_bound);
+int anirec_ingest_encode(const int32_t *id, int64_t n, int32_t id_bound, int32_t *out_index,
+                         int32_t *out_uniques, int64_t *n_unique, int32_t *err_flag, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

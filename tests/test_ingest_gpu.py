@@ -1,0 +1,151 @@
+"""Parity of the GPU ingest path (anirec_ingest_*) with the pandas restatement of the reference's
+preprocess step and id encoding (oracle/ingest_oracle.py).  Bit-exact: integer columns, order,
+float64 ratings, indices and the order of the unique-id tables."""
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from oracle import ingest_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _raw_frame(n, n_users, n_anime, seed, nulls=True, dups=True):
+    rng = np.random.default_rng(seed)
+    users = np.sort(rng.choice(np.arange(1, 5 * n_users), n_users, replace=False))
+    animes = rng.choice(np.arange(1, 3 * n_anime), n_anime, replace=False)
+    # skewed activity: some users fall below any sensible num_reviews
+    w = rng.lognormal(0, 1.2, n_users)
+    df = pd.DataFrame({
+        "user_id": users[rng.choice(n_users, n, p=w / w.sum())],
+        "anime_id": animes[rng.integers(0, n_anime, n)],
+        "rating": rng.integers(0, 11, n),
+        "watching_status": rng.choice([1, 2, 3, 4, 6], n),
+        "watched_episodes": rng.integers(0, 30, n),
+    })
+    if dups:  # exact duplicate rows scattered through the frame (first occurrence must win)
+        src = rng.integers(0, n, n // 20)
+        dst = rng.integers(0, n, n // 20)
+        df.iloc[dst] = df.iloc[src].to_numpy()
+    if nulls:
+        df = df.astype({"user_id": "float64", "anime_id": "float64", "rating": "float64",
+                        "watching_status": "float64", "watched_episodes": "float64"})
+        for col in df.columns:
+            df.loc[rng.integers(0, n, max(1, n // 500)), col] = np.nan
+    return df
+
+
+def _gpu_preprocess(df, **kw):
+    from anime_recommendations_amd import ingest
+    cols = ingest.frame_to_columns(df)
+    return {k: v.cpu().numpy() for k, v in ingest.preprocess_columns(cols, **kw).items()}
+
+
+def _check(df, num_reviews, **flags):
+    want = orc.preprocess(df, num_reviews, flags.get("drop_unwatched", False), flags.get("drop_plan", False),
+                          flags.get("drop_half_watched", False))
+    got = _gpu_preprocess(df, num_reviews=num_reviews, **flags)
+    assert len(got["user_id"]) == len(want)
+    for col in ("user_id", "anime_id", "watching_status", "watched_episodes"):
+        np.testing.assert_array_equal(got[col].astype(np.int64), want[col].to_numpy().astype(np.int64), err_msg=col)
+    w = want["rating"].to_numpy().astype(np.float64)
+    assert got["rating"].dtype == np.float64
+    np.testing.assert_array_equal(got["rating"].view(np.uint64), w.view(np.uint64))
+    return want
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(drop_unwatched=True), dict(drop_plan=True),
+                                   dict(drop_unwatched=True, drop_plan=True, drop_half_watched=True),
+                                   dict(drop_half_watched=True)])
+def test_preprocess_matches_pandas(flags):
+    df = _raw_frame(200_000, 900, 700, seed=3)
+    want = _check(df, 150, **flags)
+    assert 0 < len(want) < len(df)
+
+
+def test_preprocess_no_nulls_integer_columns():
+    df = _raw_frame(50_000, 300, 400, seed=5, nulls=False)
+    _check(df, 100)
+
+
+def test_preprocess_edge_cases():
+    # everything dropped
+    df = _raw_frame(5_000, 200, 100, seed=7)
+    got = _gpu_preprocess(df, num_reviews=10 ** 6)
+    assert all(len(v) == 0 for v in got.values())
+    # single row / constant rating: max == min, the reference's scale_ratings raises ZeroDivisionError
+    one = pd.DataFrame({"user_id": [7], "anime_id": [3], "rating": [5.0], "watching_status": [2], "watched_episodes": [1]})
+    with pytest.raises(ZeroDivisionError):
+        orc.preprocess(one, 1)
+    with pytest.raises(ZeroDivisionError):
+        _gpu_preprocess(one, num_reviews=1)
+    # the duplicate of row 0 sits at the very end; a tile-boundary sized frame
+    df = _raw_frame(4096 * 3, 50, 60, seed=9, nulls=False, dups=False)
+    df = pd.concat([df, df.iloc[[0]]], ignore_index=True)
+    _check(df, 1)
+    df = _raw_frame(4096 * 2, 50, 60, seed=10, nulls=False)
+    _check(df, 20, drop_half_watched=True)
+
+
+def test_encode_matches_series_unique():
+    from anime_recommendations_amd import ingest
+    rng = np.random.default_rng(11)
+    for n, hi in ((1, 10), (4096, 50), (300_000, 70_000), (300_001, 5)):
+        ids = rng.integers(0, hi, n).astype(np.int32) * 3 + 1
+        idx, uniq = ingest.encode_ids(torch.as_tensor(ids, device="cuda"))
+        want_idx, want_uniq = orc.encode(pd.Series(ids))
+        np.testing.assert_array_equal(idx.cpu().numpy(), want_idx)
+        np.testing.assert_array_equal(uniq.cpu().numpy(), want_uniq)
+
+
+def test_preprocess_then_encode_feeds_training_layout():
+    """End to end against data.encode_frame (the host path the trainer used so far)."""
+    from anime_recommendations_amd import data, ingest
+    df = _raw_frame(120_000, 500, 600, seed=13)
+    want_df = orc.preprocess(df, 100)
+    cols = ingest.preprocess_columns(ingest.frame_to_columns(df), num_reviews=100)
+    enc = ingest.encode_columns(cols, shuffle=True, random_state=42)
+    ref = data.encode_frame(want_df.astype({"user_id": "int64", "anime_id": "int64"}), shuffle=True, random_state=42)
+    np.testing.assert_array_equal(enc.user.cpu().numpy(), ref.user)
+    np.testing.assert_array_equal(enc.anime.cpu().numpy(), ref.anime)
+    np.testing.assert_array_equal(enc.rating.cpu().numpy(), ref.rating)
+    np.testing.assert_array_equal(enc.user_ids.cpu().numpy(), ref.user_ids)
+    np.testing.assert_array_equal(enc.anime_ids.cpu().numpy(), ref.anime_ids)
+
+
+def test_fullsize_properties_109m_rows():
+    """BASELINE size (109 M rows): no oracle run, size-independent properties instead —
+    idempotence, order preservation, per-user counts >= num_reviews, no duplicate rows."""
+    from anime_recommendations_amd import ingest
+    n, n_users, n_anime = 109_000_000, 350_000, 18_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(17)
+    cols = {
+        "user_id": torch.randint(0, n_users, (n,), generator=g, device="cuda", dtype=torch.int32),
+        "anime_id": torch.randint(0, n_anime, (n,), generator=g, device="cuda", dtype=torch.int32),
+        "rating": torch.randint(0, 11, (n,), generator=g, device="cuda", dtype=torch.int32).double(),
+        "watching_status": torch.randint(1, 7, (n,), generator=g, device="cuda", dtype=torch.int32),
+        "watched_episodes": torch.randint(0, 3, (n,), generator=g, device="cuda", dtype=torch.int32),
+    }
+    out = ingest.preprocess_columns(cols, num_reviews=300, drop_plan=True)
+    m = int(out["user_id"].numel())
+    assert 0 < m < n
+    assert int((out["watching_status"] == 6).sum()) == 0
+    cnt = torch.bincount(out["user_id"].long(), minlength=n_users)
+    assert int(cnt[cnt > 0].min()) >= 300
+    assert float(out["rating"].min()) == 0.0 and float(out["rating"].max()) == 1.0
+    # no duplicate rows survive: (user, anime, rating*10, status, episodes) packed into one int64 key
+    key = ((out["user_id"].long() * n_anime + out["anime_id"].long()) * 11 +
+           (out["rating"] * 10).round().long()) * 8 * 4 + out["watching_status"].long() * 4 + out["watched_episodes"].long()
+    assert int(torch.unique(key).numel()) == m
+    # idempotent (second scaling is (x - 0) / (1 - 0))
+    again = ingest.preprocess_columns(out, num_reviews=300, drop_plan=True)
+    for k in out:
+        assert torch.equal(again[k], out[k]), k
+    # encoding: indices are a bijection onto first-appearance order
+    idx, uniq = ingest.encode_ids(out["user_id"])
+    assert torch.equal(uniq[idx.long()], out["user_id"])
+    first = torch.full((int(uniq.numel()),), m, dtype=torch.int64, device="cuda")
+    first.scatter_reduce_(0, idx.long(), torch.arange(m, device="cuda"), reduce="amin")
+    assert bool((first[1:] > first[:-1]).all())

@@ -133,3 +133,29 @@ def test_predict_matches_eval_forward():
     assert G.shape == (2, 11) and np.all((G > 0) & (G < 1))
     p = orc.predict_pairs(U, A, head, np.array([5]), np.array([7]))
     assert p[0] == G[1, 7]
+
+
+def test_ingest_oracle_hand_example():
+    """Pins the pandas restatement of preprocess.py on a frame small enough to do by hand."""
+    import pandas as pd
+    from oracle import ingest_oracle as ing
+    df = pd.DataFrame({
+        "user_id":          [10, 10, 20, 10, 20, 30, 10, 20],
+        "anime_id":         [5,  6,  5,  5,  7,  5,  8,  9],
+        "rating":           [8,  2,  10, 8,  6,  9,  4,  np.nan],
+        "watching_status":  [2,  2,  2,  2,  6,  2,  2,  2],
+        "watched_episodes": [12, 0,  12, 12, 3,  1,  6,  2],
+    })
+    # row 3 duplicates row 0; row 7 has a NaN; user 30 has one rating
+    out = ing.preprocess(df, num_reviews=2)
+    assert out["user_id"].tolist() == [10, 10, 20, 20, 10]
+    assert out["anime_id"].tolist() == [5, 6, 5, 7, 8]
+    assert out["rating"].tolist() == [(8 - 2) / 8, 0.0, 1.0, (6 - 2) / 8, (4 - 2) / 8]
+    out = ing.preprocess(df, num_reviews=2, drop_unwatched=True, drop_plan=True)
+    # after the row filters user 20 keeps one rating and is dropped; user 10 keeps rows 0 and 6
+    assert out["user_id"].tolist() == [10, 10] and out["rating"].tolist() == [1.0, 0.0]
+    out = ing.preprocess(df, num_reviews=1, drop_half=True)
+    # per-anime max watched: 5 -> 12, 6 -> 0, 7 -> 3, 8 -> 6; user 30's single episode of anime 5 is < 6
+    assert out["anime_id"].tolist() == [5, 6, 5, 7, 8]
+    idx, uniq = ing.encode(pd.Series([7, 3, 7, 9, 3]))
+    assert idx.tolist() == [0, 1, 0, 2, 1] and uniq.tolist() == [7, 3, 9]
