@@ -36,11 +36,11 @@ def main():
     with open(os.path.join(OUT, "reference_output_formats.json"), "w") as f:
         json.dump(fmt, f, indent=1, ensure_ascii=False)
 
-    # the CLI surface of the four hot-path components: flag names and which are booleans
+    # the CLI surface of the four hot-path components and of the preprocess step before them: flag names and which are booleans
     # (reference <c>/<c>.py argparse blocks + <c>/MLproject parameter lists)
     import re
     flags = {}
-    for c in ("neural_network", "similar_anime", "similar_users", "model_recs"):
+    for c in ("neural_network", "similar_anime", "similar_users", "model_recs", "preprocess"):
         src = open("/root/reference/%s/%s.py" % (c, c)).read()
         found = re.findall(r'add_argument\(\s*"--(\w+)",\s*type=([^,]+),', src)
         ml = open("/root/reference/%s/MLproject" % c).read()

@@ -169,3 +169,38 @@ def test_model_recs_component(pipeline, golden_dir):
     np.testing.assert_allclose(out["Prediction"].to_numpy(), op, atol=1e-5)     # BASELINE bar
     if np.abs(np.diff(np.sort(p[keep])[::-1][:11])).min() > 2e-6:
         assert out["anime_id"].tolist() == ids[oi].tolist()
+
+
+def test_preprocess_component(tmp_path):
+    """preprocess step run with the reference's flag set: the logged parquet equals the pandas
+    restatement of preprocess.py (same rows, order, dtypes, float64 ratings)."""
+    from anime_recommendations_amd import artifacts
+    from oracle import ingest_oracle
+    rng = np.random.default_rng(21)
+    n = 60_000
+    raw = pd.DataFrame({"user_id": rng.integers(1, 400, n), "anime_id": rng.integers(1, 900, n),
+                        "rating": rng.integers(0, 11, n), "watching_status": rng.choice([1, 2, 3, 4, 6], n),
+                        "watched_episodes": rng.integers(0, 26, n)})
+    raw.iloc[rng.integers(0, n, 2000)] = raw.iloc[rng.integers(0, n, 2000)].to_numpy()   # duplicate rows
+    env = dict(os.environ, ANIREC_ARTIFACT_DIR=str(tmp_path / "store"))
+    old = os.environ.get("ANIREC_ARTIFACT_DIR")
+    os.environ["ANIREC_ARTIFACT_DIR"] = env["ANIREC_ARTIFACT_DIR"]
+    try:
+        raw_path = str(tmp_path / "animelist.parquet")
+        raw.to_parquet(raw_path, index=False)
+        artifacts.log_artifact("all_user_stats.parquet", raw_path, "Raw data")
+        flags = dict(raw_stats="all_user_stats.parquet:latest", project_name="anime_recommendations",
+                     preprocessed_stats="preprocessed_stats.parquet", preprocessed_artifact_type="preprocessed_data",
+                     preprocessed_artifact_description="d", num_reviews=120, drop_half_watched=False,
+                     save_clean_locally=False, drop_unwatched=True, drop_plan=True)
+        _run("preprocess", flags, str(tmp_path), env)
+        got = pd.read_parquet(artifacts.use_artifact("preprocessed_stats.parquet:latest", "preprocessed_data"))
+    finally:
+        if old is None:
+            os.environ.pop("ANIREC_ARTIFACT_DIR", None)
+        else:
+            os.environ["ANIREC_ARTIFACT_DIR"] = old
+    want = ingest_oracle.preprocess(raw, 120, drop_unwatched=True, drop_plan=True).reset_index(drop=True)
+    assert list(got.columns) == list(want.columns) and len(got) == len(want) > 0
+    assert not os.path.exists(tmp_path / "preprocessed_stats.parquet")      # save_clean_locally False
+    pd.testing.assert_frame_equal(got, want, check_exact=True)

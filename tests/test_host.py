@@ -76,7 +76,7 @@ def test_model_container_roundtrip(tmp_path):
         weights_io.load_model(p, user_name="nope")
 
 
-@pytest.mark.parametrize("comp", ["neural_network", "similar_anime", "similar_users", "model_recs"])
+@pytest.mark.parametrize("comp", ["neural_network", "similar_anime", "similar_users", "model_recs", "preprocess"])
 def test_component_flag_surface_matches_reference(comp, golden_dir):
     ref = json.load(open(os.path.join(golden_dir, "component_flags.json")))[comp]
     spec = importlib.util.spec_from_file_location(comp + "_cli", os.path.join(ROOT, comp, comp + ".py"))
