@@ -51,10 +51,21 @@ __device__ __forceinline__ bool row_eq(const IngestCols &c, int64_t i, int64_t j
          c.episodes[i] == c.episodes[j] && rating_bits(c.rating[i]) == rating_bits(c.rating[j]);
 }
 
+// order-preserving double <-> uint64 (for atomicMin / atomicMax)
+__device__ __forceinline__ unsigned long long d2ord(double d) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+__host__ __device__ inline double ord2d(unsigned long long o) {
+  const unsigned long long b = (o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFULL) : ~o;
+  double d;
+  memcpy(&d, &b, 8);
+  return d;
+}
 // dropna + the two row-local filters (they commute with drop_duplicates: duplicates share their fate)
 __global__ __launch_bounds__(256) void k_ing_alive(IngestCols c, int64_t n, int drop_unwatched, int drop_plan,
                                                    int user_bound, int anime_bound, uint8_t *alive,
-                                                   int32_t *err) {
+                                                   uint8_t *keep, int32_t *err) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int32_t u = c.user[i], a = c.anime[i], s = c.status[i], e = c.episodes[i];
@@ -68,47 +79,101 @@ __global__ __launch_bounds__(256) void k_ing_alive(IngestCols c, int64_t n, int 
     if (ok && drop_unwatched && e == 0) ok = false;
     if (ok && drop_plan && s == 6) ok = false;
     alive[i] = ok ? 1 : 0;
+    keep[i] = ok ? 1 : 0;  // k_ing_insert clears the later members of every class of identical rows
   }
 }
 
-// drop_duplicates(keep='first'): every class of identical rows owns one table slot holding the
-// SMALLEST row index of the class (atomicMin), whatever the insertion order
-__global__ __launch_bounds__(256) void k_ing_insert(IngestCols c, int64_t n, const uint8_t *alive, int32_t *table,
-                                                    uint32_t mask) {
+// drop_duplicates(keep='first'): every class of identical rows owns one table slot that ends up
+// holding the SMALLEST row index of the class, whatever the insertion order: a row that meets an equal
+// row in its slot does atomicMin(slot, i); the larger of (i, previous owner) has lost and its keep
+// flag is cleared — the final owner is never cleared, every other member exactly once.  No pass over
+// the table is needed afterwards.
+// A slot is {upper 32 hash bits, row index}: a probe that lands on another class is rejected by the
+// tag without touching that row's five columns (five random sectors).
+__global__ __launch_bounds__(256) void k_ing_insert(IngestCols c, int64_t n, const uint8_t *alive,
+                                                    unsigned long long *table, uint32_t mask, uint8_t *keep) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     if (!alive[i]) continue;
-    uint32_t s = (uint32_t)row_hash(c, i) & mask;
+    const uint64_t h = row_hash(c, i);
+    const unsigned long long entry = (h & 0xFFFFFFFF00000000ULL) | (uint32_t)i;
+    uint32_t s = (uint32_t)h & mask;
     for (;;) {
-      const int32_t old = atomicCAS(&table[s], -1, (int32_t)i);
-      if (old == -1) break;
-      if (row_eq(c, i, old)) {
-        atomicMin(&table[s], (int32_t)i);
+      const unsigned long long old = atomicCAS(&table[s], ~0ULL, entry);
+      if (old == ~0ULL) break;
+      if ((old >> 32) == (entry >> 32) && row_eq(c, i, (int64_t)(uint32_t)old)) {
+        // same tag: the 64-bit minimum is the minimum row index; prev is a member of the same class
+        const unsigned long long prev = atomicMin(&table[s], entry);
+        keep[prev > entry ? (uint32_t)prev : (uint32_t)i] = 0;
         break;
       }
       s = (s + 1) & mask;
     }
   }
 }
-__global__ __launch_bounds__(256) void k_ing_mark(const int32_t *table, uint32_t slots, uint8_t *keep) {
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < slots; s += stride) {
-    const int32_t j = table[s];
-    if (j >= 0) keep[j] = 1;
+
+// value_counts() of user_id over the surviving rows.  The raw table is grouped by user (ascending
+// blocks of user_id), so consecutive rows mostly share their user: a wave adds one atomic per RUN of
+// equal ids among its 64 consecutive rows instead of one per row.
+__global__ __launch_bounds__(256) void k_ing_count(const int32_t *id, int64_t n, const uint8_t *keep, int32_t *cnt) {
+  const int lane = lane_id();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n_round = (n + 63) / 64 * 64;  // whole waves stay converged for the shuffles
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+    const int32_t key = (i < n && keep[i]) ? id[i] : -1;
+    const int32_t left = __shfl_up(key, 1, 64);
+    const bool head = lane == 0 || key != left;
+    const unsigned long long heads = __ballot(head);
+    if (head && key >= 0) {
+      const unsigned long long later = lane == 63 ? 0ULL : heads >> (lane + 1);
+      const int len = later ? __ffsll((long long)later) : 64 - lane;
+      atomicAdd(&cnt[key], len);
+    }
   }
 }
-
-// value_counts() of user_id over the surviving rows, then the num_reviews filter
-__global__ __launch_bounds__(256) void k_ing_count(const int32_t *id, int64_t n, const uint8_t *keep, int32_t *cnt) {
+// the num_reviews filter; when it is the last filter it also reduces min / max of the ratings
+template <bool kMinMax>
+__global__ __launch_bounds__(256) void k_ing_user_filter(const int32_t *user, const double *rating, int64_t n,
+                                                         const int32_t *cnt, int num_reviews, uint8_t *keep,
+                                                         unsigned long long *mm) {
+  unsigned long long lo = ~0ULL, hi = 0ULL;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    if (keep[i]) atomicAdd(&cnt[id[i]], 1);
-}
-__global__ __launch_bounds__(256) void k_ing_user_filter(const int32_t *user, int64_t n, const int32_t *cnt,
-                                                         int num_reviews, uint8_t *keep) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    if (keep[i] && cnt[user[i]] < num_reviews) keep[i] = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (!keep[i]) continue;
+    if (cnt[user[i]] < num_reviews) {
+      keep[i] = 0;
+      continue;
+    }
+    if (kMinMax) {
+      const unsigned long long o = d2ord(rating[i]);
+      lo = o < lo ? o : lo;
+      hi = o > hi ? o : hi;
+    }
+  }
+  if (kMinMax) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const unsigned long long l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+      lo = l2 < lo ? l2 : lo;
+      hi = h2 > hi ? h2 : hi;
+    }
+    __shared__ unsigned long long red[2][4];
+    if (lane_id() == 0) {
+      red[0][threadIdx.x >> 6] = lo;
+      red[1][threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // one pair of atomics per workgroup
+      for (int w = 1; w < 4; ++w) {
+        lo = red[0][w] < lo ? red[0][w] : lo;
+        hi = red[1][w] > hi ? red[1][w] : hi;
+      }
+      if (lo <= hi) {
+        atomicMin(&mm[0], lo);
+        atomicMax(&mm[1], hi);
+      }
+    }
+  }
 }
 // groupby('anime_id')['watched_episodes'].max(), then keep watched >= (max == 1 ? 1 : max * .5)
 __global__ __launch_bounds__(256) void k_ing_anime_max(IngestCols c, int64_t n, const uint8_t *keep, int32_t *mx) {
@@ -126,17 +191,6 @@ __global__ __launch_bounds__(256) void k_ing_half_filter(IngestCols c, int64_t n
   }
 }
 
-// order-preserving double <-> uint64 (for atomicMin / atomicMax)
-__device__ __forceinline__ unsigned long long d2ord(double d) {
-  const unsigned long long b = (unsigned long long)__double_as_longlong(d);
-  return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
-}
-__host__ __device__ inline double ord2d(unsigned long long o) {
-  const unsigned long long b = (o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFULL) : ~o;
-  double d;
-  memcpy(&d, &b, 8);
-  return d;
-}
 // min(df['rating']), max(df['rating']) over the surviving rows
 __global__ __launch_bounds__(256) void k_ing_minmax(const double *rating, int64_t n, const uint8_t *keep,
                                                     unsigned long long *mm) {
@@ -249,14 +303,22 @@ __global__ __launch_bounds__(256) void k_ing_compact(IngestCols c, int64_t n, co
 
 // ---- Series.unique() encoding: dense index = rank of the id's first appearance ----
 __global__ __launch_bounds__(256) void k_enc_first(const int32_t *id, int64_t n, int bound, int32_t *first, int32_t *err) {
+  const int lane = lane_id();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int32_t v = id[i];
-    if (v < 0 || v >= bound) {
+  const int64_t n_round = (n + 63) / 64 * 64;  // whole waves stay converged for the shuffle
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+    int32_t v = i < n ? id[i] : -1;
+    if (i < n && (v < 0 || v >= bound)) {
       *err = 1;
-      continue;
+      v = -1;
     }
-    atomicMin(&first[v], (int32_t)i);
+    // A table grouped by user presents runs of equal ids to a wave: only the first lane of a run (the
+    // smallest row index of the run) goes to memory.  It reads first (at L2, where the atomics land: an
+    // L1 line would stay stale), so that after its first few rows an id costs no atomic at all.
+    const int32_t left = __shfl_up(v, 1, 64);
+    const bool head = lane == 0 || v != left;
+    if (head && v >= 0 && __hip_atomic_load(&first[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (int32_t)i)
+      atomicMin(&first[v], (int32_t)i);
   }
 }
 __global__ __launch_bounds__(256) void k_enc_flag(const int32_t *id, int64_t n, int bound, const int32_t *first,
@@ -314,7 +376,7 @@ extern "C" {
 size_t anirec_ingest_workspace_bytes(int64_t n, int32_t user_id_bound, int32_t anime_id_bound) {
   if (n < 1 || n >= ((int64_t)1 << 30) || user_id_bound < 1 || anime_id_bound < 1) return 0;
   const size_t np = pad_tile(n);
-  return 2 * al256(np) + al256(np * 4) + al256(np / kScanTile * 4) + al256((size_t)table_slots(n) * 4) +
+  return 2 * al256(np) + al256(np * 4) + al256(np / kScanTile * 4) + al256((size_t)table_slots(n) * 8) +
          al256((size_t)user_id_bound * 4) + al256((size_t)anime_id_bound * 4) + 256;
 }
 
@@ -341,8 +403,8 @@ int anirec_ingest_preprocess(const int32_t *user_id, const int32_t *anime_id, co
   p += al256(np * 4);
   int32_t *bsum = (int32_t *)p;
   p += al256(np / kScanTile * 4);
-  int32_t *table = (int32_t *)p;
-  p += al256((size_t)slots * 4);
+  unsigned long long *table = (unsigned long long *)p;
+  p += al256((size_t)slots * 8);
   int32_t *cnt_u = (int32_t *)p;
   p += al256((size_t)opts->user_id_bound * 4);
   int32_t *max_ep = (int32_t *)p;
@@ -352,26 +414,29 @@ int anirec_ingest_preprocess(const int32_t *user_id, const int32_t *anime_id, co
   const IngestCols c{user_id, anime_id, rating, watching_status, watched_episodes};
   const int g = grid_for(n);
   ANIREC_HIP_CHECK(hipMemsetAsync(err_flag, 0, 4, s));
-  ANIREC_HIP_CHECK(hipMemsetAsync(keep, 0, np, s));
+  ANIREC_HIP_CHECK(hipMemsetAsync(keep + n, 0, np - (size_t)n, s));
   ANIREC_HIP_CHECK(hipMemsetAsync(alive + n, 0, np - (size_t)n, s));
-  ANIREC_HIP_CHECK(hipMemsetAsync(table, 0xFF, (size_t)slots * 4, s));
+  ANIREC_HIP_CHECK(hipMemsetAsync(table, 0xFF, (size_t)slots * 8, s));
   ANIREC_HIP_CHECK(hipMemsetAsync(cnt_u, 0, (size_t)opts->user_id_bound * 4, s));
   ANIREC_HIP_CHECK(hipMemsetAsync(mm, 0xFF, 8, s));
   ANIREC_HIP_CHECK(hipMemsetAsync(mm + 1, 0, 8, s));
   hipLaunchKernelGGL(k_ing_alive, dim3(g), dim3(256), 0, s, c, n, opts->drop_unwatched, opts->drop_plan,
-                     opts->user_id_bound, opts->anime_id_bound, alive, err_flag);
-  hipLaunchKernelGGL(k_ing_insert, dim3(g), dim3(256), 0, s, c, n, alive, table, slots - 1);
-  hipLaunchKernelGGL(k_ing_mark, dim3(grid_for(slots)), dim3(256), 0, s, table, slots, keep);
+                     opts->user_id_bound, opts->anime_id_bound, alive, keep, err_flag);
+  hipLaunchKernelGGL(k_ing_insert, dim3(g), dim3(256), 0, s, c, n, alive, table, slots - 1, keep);
   hipLaunchKernelGGL(k_ing_count, dim3(g), dim3(256), 0, s, user_id, n, keep, cnt_u);
-  hipLaunchKernelGGL(k_ing_user_filter, dim3(g), dim3(256), 0, s, user_id, n, cnt_u, opts->num_reviews, keep);
-  if (opts->drop_half_watched) {
+  if (!opts->drop_half_watched) {
+    hipLaunchKernelGGL(k_ing_user_filter<true>, dim3(g > 4096 ? 4096 : g), dim3(256), 0, s, user_id, rating, n, cnt_u,
+                       opts->num_reviews, keep, mm);
+  } else {
+    hipLaunchKernelGGL(k_ing_user_filter<false>, dim3(g), dim3(256), 0, s, user_id, rating, n, cnt_u,
+                       opts->num_reviews, keep, mm);
     // episodes can be any int32: start the per-anime maxima at INT32_MIN (0x80 bytes give 0x80808080 < 0,
     // below every non-null value is not guaranteed, so set exactly)
     ANIREC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)max_ep, (int)0x80000000, (size_t)opts->anime_id_bound, s));
     hipLaunchKernelGGL(k_ing_anime_max, dim3(g), dim3(256), 0, s, c, n, keep, max_ep);
     hipLaunchKernelGGL(k_ing_half_filter, dim3(g), dim3(256), 0, s, c, n, max_ep, keep);
+    hipLaunchKernelGGL(k_ing_minmax, dim3(g > 2048 ? 2048 : g), dim3(256), 0, s, rating, n, keep, mm);
   }
-  hipLaunchKernelGGL(k_ing_minmax, dim3(g > 2048 ? 2048 : g), dim3(256), 0, s, rating, n, keep, mm);
   ANIREC_HIP_CHECK(hipGetLastError());
   int rc = scan_flags(keep, n, bsum, pos, n_out, s);
   if (rc) return rc;
