@@ -108,6 +108,9 @@ PROTOTYPES = {
     "anirec_predict_grid_mfma": (C.c_int, [_vp, _vp, _i32, _vp, _i32, C.POINTER(Head), _vp, _vp, _sz, _vp]),
     "anirec_predict_topk": (C.c_int, [_vp, _vp, _i32, _vp, _i32, C.POINTER(Head), _vp, _i32, _vp,
                                       _vp, _vp, _sz, _vp]),
+    "anirec_predict_topk_mfma_workspace_bytes": (_sz, [_i32, _i32]),
+    "anirec_predict_topk_mfma": (C.c_int, [_vp, _vp, _i32, _vp, _i32, C.POINTER(Head), _vp, _i32, _vp,
+                                           _vp, _vp, _vp, _sz, _vp]),
     "anirec_ingest_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "anirec_ingest_preprocess": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(IngestOpts), _vp, _vp, _vp,
                                            _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -3,6 +3,7 @@
 // HALF-wave (32 lanes x 16 B = 512 B, one fully coalesced request).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "../../include/anirec.h"
@@ -87,6 +88,20 @@ __device__ __forceinline__ float sigmoidf_stable(float y) {
   float e = __expf(-fabsf(y));
   // expf via the fast path is within 2 ulp; the 1e-5 tolerance on ratings absorbs it
   return y >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+}
+
+// rating of a pair from its cosine through the folded BN-inference head: ONE definition shared by the
+// exact path (k_scores epilogue) and the MFMA path's re-rank, so both produce the same fp32 value
+__device__ __forceinline__ float rating_from_cosine(float c, float hs, float hb) {
+  return sigmoidf_stable(__fmaf_rn(c, hs, hb));
+}
+
+// sigmoid(gamma*(w*c+b-mu)/sqrt(var+eps)+beta) = sigmoid(c*hs + hb); folded in fp32 exactly as
+// tf.nn.batch_normalization does: inv = rsqrt(var+eps)*gamma; y = z*inv + (beta - mu*inv)
+static inline void head_affine_f32(const anirec_head *h, float *hs, float *hb) {
+  const float inv = (1.0f / sqrtf(h->mov_var + kBnEps)) * h->gamma;
+  *hs = h->w * inv;
+  *hb = h->b * inv + (h->beta - h->mov_mean * inv);
 }
 
 }  // namespace anirec

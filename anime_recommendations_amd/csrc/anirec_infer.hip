@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_scores(ScoreArgs a) {
       const int j = j0 + tx + 16 * r;
       if (j >= a.n) continue;
       float s = acc[qq][r];
-      if (a.use_head) s = sigmoidf_stable(s * a.hs + a.hb);
+      if (a.use_head) s = rating_from_cosine(s, a.hs, a.hb);
       a.out[(size_t)q * a.ld + j] = s;
     }
   }
@@ -358,13 +358,7 @@ __global__ void k_fill_self(const int32_t *queries, int nq, int32_t *self, int e
   if (i < nq) self[i] = enable ? queries[i] : -1;
 }
 
-static inline void head_affine(const anirec_head *h, float *hs, float *hb) {
-  // sigmoid(gamma*(w*c+b-mu)/sqrt(var+eps)+beta) = sigmoid(c*hs + hb); folded in fp32 exactly as
-  // tf.nn.batch_normalization does: inv = rsqrt(var+eps)*gamma; y = z*inv + (beta - mu*inv)
-  const float inv = (1.0f / sqrtf(h->mov_var + kBnEps)) * h->gamma;
-  *hs = h->w * inv;
-  *hb = h->b * inv + (h->beta - h->mov_mean * inv);
-}
+static inline void head_affine(const anirec_head *h, float *hs, float *hb) { head_affine_f32(h, hs, hb); }
 
 static int launch_scores(const ScoreArgs &a, hipStream_t s) {
   dim3 grid((a.n + kTile - 1) / kTile, (a.nq + kTile - 1) / kTile);

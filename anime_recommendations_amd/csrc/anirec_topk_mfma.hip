@@ -88,6 +88,37 @@ __global__ __launch_bounds__(256) void k_to_f16(const float *W, const int32_t *r
   }
 }
 
+// model.predict operands: tf l2_normalize (x * rsqrt(max(sum x^2, 1e-12)), the same expressions as
+// k_rownorm<1> of anirec_infer.hip) of a gathered row -> fp32 copy for the exact re-rank and fp16 copy,
+// multiplied by `sign`, for the MFMA (sign = -1 turns "largest rating" into "largest score" when the
+// folded head slope is negative).  Rows n .. n_pad-1 of the fp16 output are NaN rows (tile padding).
+__global__ __launch_bounds__(256) void k_norm_f16(const float *W, const int32_t *rows, int n, int n_pad, float sign,
+                                                  float *out32, _Float16 *out16) {
+  const int l = threadIdx.x & 31;
+  const int nhw = gridDim.x * 8;
+  for (int r = blockIdx.x * 8 + (threadIdx.x >> 5); r < n_pad; r += nhw) {
+    if (r >= n) {
+      reinterpret_cast<uint2 *>(out16)[(size_t)r * kRowVec + l] = make_uint2(0x7E007E00u, 0x7E007E00u);
+      continue;
+    }
+    const int src = rows ? rows[r] : r;
+    float4 x = reinterpret_cast<const float4 *>(W)[(size_t)src * kRowVec + l];
+    float ss = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+    ss = halfwave_sum(ss);
+    const float rinv = 1.0f / sqrtf(fmaxf(ss, kL2nEps));
+    float4 y;
+    y.x = x.x * rinv;
+    y.y = x.y * rinv;
+    y.z = x.z * rinv;
+    y.w = x.w * rinv;
+    reinterpret_cast<float4 *>(out32)[(size_t)r * kRowVec + l] = y;
+    _Float16 o[4] = {(_Float16)(y.x * sign), (_Float16)(y.y * sign), (_Float16)(y.z * sign), (_Float16)(y.w * sign)};
+    uint2 v = *reinterpret_cast<uint2 *>(o);
+    if (y.x != y.x || y.y != y.y || y.z != y.z || y.w != y.w) v = make_uint2(0u, 0u);  // NaN row: flagged by the re-rank
+    reinterpret_cast<uint2 *>(out16)[(size_t)r * kRowVec + l] = v;
+  }
+}
+
 struct CandArgs {
   const uint4 *Qb;   // [nq][16] 16-B chunks of fp16 query rows
   const uint4 *Wb;   // [n][16]
@@ -98,6 +129,8 @@ struct CandArgs {
   float *theta;      // [nq]
   int32_t *flags;    // [nq] bit0: buffer overflow (dense ties)
   unsigned long long *dbg;  // kDbg == 2: [0] total appends
+  const uint32_t *watched;  // kMask: [nq][wwords] per-query key mask, bit set = key excluded (model_recs)
+  int wwords;
 };
 
 // ------------------------------------------------------------------------------------
@@ -165,7 +198,9 @@ __global__ __launch_bounds__(64) void k_refresh(CandArgs a) {
 // ------------------------------------------------------------------------------------
 // kWaves = 8 (256 query rows per workgroup, one workgroup per CU) halves the L2 -> LDS key traffic per
 // MFMA and is used when the queries fill the chip that way; kWaves = 4 (two workgroups per CU) otherwise.
-template <int kDbg, int kWaves>  // kDbg 0: product; 1: no filter (timing experiments only); 2: count appends; 4: stamps
+// kMask: a candidate is dropped at append time when its bit in the query's own mask row is set (the
+// "already watched" set of model_recs); one extra load on the rare append path, nothing in the MFMA loop.
+template <int kDbg, int kWaves, bool kMask = false>  // kDbg 0: product; 1: no filter (timing only); 2: count appends; 4: stamps
 __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
   constexpr int kBM = 32 * kWaves;
   constexpr int kDma = 32 / kWaves;  // LDS-DMA instructions per wave per key tile (4 key rows each)
@@ -306,11 +341,16 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
         const int key = key0 + 16 * nb + c16;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const unsigned long long mk = __ballot(cv[i] >= 0.f);
+          bool hit = cv[i] >= 0.f;
+          if (kMask && hit) {  // dead rows (C-in = -inf) never get here: the mask row exists
+            const size_t rl = (size_t)(q0 + 32 * w + 16 * rb + 4 * gq + i);
+            hit = ((a.watched[rl * a.wwords + (key >> 5)] >> (key & 31)) & 1u) == 0u;
+          }
+          const unsigned long long mk = __ballot(hit);
           if (mk) {  // wave-uniform
             const uint32_t mh = (uint32_t)(mk >> sh16) & 0xFFFFu;  // the quarter-wave (= row) of this lane
             const uint32_t pos = (uint32_t)cntr[rb][i] + __popc(mh & lt16);
-            if (cv[i] >= 0.f && pos < (uint32_t)kCap)
+            if (hit && pos < (uint32_t)kCap)
               *reinterpret_cast<uint2 *>(cand_bytes + (rowoff[rb][i] + pos * 8u)) =
                   make_uint2(__float_as_uint(cv[i] - nthr[rb][i]), (uint32_t)key);
             cntr[rb][i] += __popc(mh);
@@ -404,10 +444,18 @@ struct RerankArgs {
   int32_t *flags;          // bit1: incomplete window / too many survivors / too few candidates
   int32_t *out_idx;        // [nq][k]
   float *out_score;        // [nq][k]
+  float hs, hb, sign;      // kPredict: rating = sigmoid(c * hs + hb); MFMA scores are sign * c
 };
 
 constexpr int kMaxSurv = 256;
 
+// kPredict (model_recs): the buffer holds MFMA values of sign * cosine; survivors are re-scored with the
+// exact cosine chain, mapped through the BN-inference head exactly as the exact path does
+// (rating_from_cosine) and ranked by (rating desc, index asc).  Ratings are a non-decreasing function of
+// sign * c, so every key that is not a survivor has rating <= rating(tau - eps): the row is complete iff
+// k survivors lie strictly above that bound (a few ulps of slack for the fast exp); saturated heads and
+// worst-case MFMA errors fail the test and fall back to the exact path.
+template <bool kPredict>
 __global__ __launch_bounds__(64) void k_rerank(RerankArgs a) {
   __shared__ float qs[kDim];
   __shared__ int32_t sidx[kMaxSurv];
@@ -416,8 +464,8 @@ __global__ __launch_bounds__(64) void k_rerank(RerankArgs a) {
   const int row = blockIdx.x;
   const size_t base = (size_t)row * kCap;
   const int c = a.cnt[row];
-  const int qrow = a.qidx[row];
-  const int self = a.exclude_self ? qrow : -1;
+  const int qrow = kPredict ? -1 : a.qidx[row];
+  const int self = (!kPredict && a.exclude_self) ? qrow : -1;
   // query row (fp32) into LDS
   {
     const float *q = a.Qf ? a.Qf + (size_t)row * kDim : a.What + (size_t)qrow * kDim;
@@ -486,9 +534,27 @@ __global__ __launch_bounds__(64) void k_rerank(RerankArgs a) {
       s = __fmaf_rn(x.z, qs[4 * k4 + 2], s);
       s = __fmaf_rn(x.w, qs[4 * k4 + 3], s);
     }
-    sval[i] = s;
+    sval[i] = kPredict ? rating_from_cosine(s, a.hs, a.hb) : s;
   }
   __syncthreads();
+  if (kPredict) {
+    // k-th best rating among the survivors vs the best any excluded key could reach
+    // keys that are not survivors have MFMA value < tau - 2 eps, i.e. sign * c < tau - eps
+    const float p_bound = rating_from_cosine(a.sign * (lo + kEpsMfma), a.hs, a.hb) * (1.0f + 6e-7f);
+    int above = 0;  // survivors strictly above the bound
+    for (int i0 = 0; i0 < ns; i0 += 64) {
+      const int i = i0 + lane;
+      above += __popcll(__ballot(i < ns && sval[i] > p_bound));
+    }
+    if (above < min(a.k, ns) || !(p_bound == p_bound)) {  // (ns >= k here: c >= kk was checked)
+      if (lane == 0) a.flags[row] |= 2;
+      for (int i = lane; i < a.k; i += 64) {
+        a.out_idx[(size_t)row * a.k + i] = -1;
+        a.out_score[(size_t)row * a.k + i] = __uint_as_float(0x7FC00000u);
+      }
+      return;
+    }
+  }
   // rank by (score desc, index asc); the query itself is dropped
   for (int i = lane; i < ns; i += 64) {
     const int mi = sidx[i];
@@ -518,6 +584,16 @@ __global__ __launch_bounds__(64) void k_rerank(RerankArgs a) {
   }
 }
 
+__global__ void k_flag_all(int32_t *flags, int nq, int32_t *out_idx, float *out_p, int k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  flags[i] = 2;
+  for (int j = 0; j < k; ++j) {
+    out_idx[(size_t)i * k + j] = -1;
+    out_p[(size_t)i * k + j] = __uint_as_float(0x7FC00000u);
+  }
+}
+
 __global__ void k_count_flags(const int32_t *flags, int nq, int32_t *count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nq && flags[i]) atomicAdd(count, 1);
@@ -531,6 +607,99 @@ using namespace anirec;
 static bool g_time_cand = false;
 static float g_cand_ms = 0.f;     // sum of the k_cand launch durations of the last call
 static int g_cand_launches = 0;
+
+// Super-steps of the key stream: thresholds are fixed inside a launch and refreshed between launches;
+// each super-step doubles the number of keys seen, so a row gains about k_eff new candidates per
+// super-step (the first one, with no threshold yet, must fit the buffer).
+static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, void *dbg_words,
+                           unsigned long long *stamps, size_t n_waves, hipStream_t s) {
+  const int ntiles = (n + kBN - 1) / kBN;
+  // 256-row workgroups once they give every CU one (8 waves per CU either way); 128-row otherwise
+  const char *wv = getenv("ANIREC_TOPK_WAVES");
+  const bool wide = wv ? atoi(wv) == 8 : nq >= 49152;
+  const dim3 grid(wide ? (nq + 255) / 256 : (nq + 127) / 128);
+  const dim3 block(wide ? 512 : 256);
+  int n_launch = 0;
+  std::vector<hipEvent_t> timed;  // event pairs around the k_cand launches (timing mode only)
+  const char *gp = getenv("ANIREC_TOPK_GROWTH");
+  const int growth_pct = gp ? atoi(gp) : 100;
+  for (int t0 = 0, step = (kCap - kBN) / kBN; t0 < ntiles;) {
+    const int t1 = t0 + step < ntiles ? t0 + step : ntiles;
+    ca.tile0 = t0;
+    ca.tile1 = t1;
+#define ANIREC_LAUNCH_CAND(D, M)                                           \
+  do {                                                                     \
+    if (wide)                                                              \
+      hipLaunchKernelGGL((k_cand<D, 8, M>), grid, block, 0, s, ca);        \
+    else                                                                   \
+      hipLaunchKernelGGL((k_cand<D, 4, M>), grid, block, 0, s, ca);        \
+  } while (0)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (g_time_cand) {
+      ANIREC_HIP_CHECK(hipEventCreate(&ev0));
+      ANIREC_HIP_CHECK(hipEventCreate(&ev1));
+      ANIREC_HIP_CHECK(hipEventRecord(ev0, s));
+    }
+    if (masked)
+      ANIREC_LAUNCH_CAND(0, true);
+    else if (mode == 1)
+      ANIREC_LAUNCH_CAND(1, false);
+    else if (mode == 2)
+      ANIREC_LAUNCH_CAND(2, false);
+    else if (mode == 4)
+      ANIREC_LAUNCH_CAND(4, false);
+    else
+      ANIREC_LAUNCH_CAND(0, false);
+#undef ANIREC_LAUNCH_CAND
+    if (g_time_cand) {
+      ANIREC_HIP_CHECK(hipEventRecord(ev1, s));
+      timed.push_back(ev0);
+      timed.push_back(ev1);
+    }
+    if (t1 < ntiles) hipLaunchKernelGGL(k_refresh, dim3(nq), dim3(64), 0, s, ca);
+    ANIREC_HIP_CHECK(hipGetLastError());
+    step = (int)((long long)t1 * growth_pct / 100);  // next super-step: growth_pct % of the tiles seen so far
+    if (step < 1) step = 1;
+    t0 = t1;
+    ++n_launch;
+  }
+  if (g_time_cand) {  // blocking: only bench.py's roofline leg arms this
+    g_cand_ms = 0.f;
+    g_cand_launches = (int)timed.size() / 2;
+    for (size_t i = 0; i + 1 < timed.size(); i += 2) {
+      float ms = 0.f;
+      (void)hipEventSynchronize(timed[i + 1]);
+      (void)hipEventElapsedTime(&ms, timed[i], timed[i + 1]);
+      g_cand_ms += ms;
+      (void)hipEventDestroy(timed[i]);
+      (void)hipEventDestroy(timed[i + 1]);
+    }
+  }
+  if (mode == 2 && !masked) {
+    unsigned long long hv[2] = {0, 0};
+    (void)hipMemcpyAsync(hv, dbg_words, 16, hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    fprintf(stderr, "[anirec topk debug] nq=%d n=%d appends/row=%.1f super-steps=%d\n", nq, n,
+            (double)hv[0] / nq, n_launch);
+  }
+  if (mode == 4 && !masked) {  // stamps of the LAST super-step
+    std::vector<unsigned long long> hv(n_waves * 4);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(hv.data(), stamps, n_waves * 32, hipMemcpyDeviceToHost);
+    (void)hipFree(stamps);
+    double tot = 0, st = 0, br = 0;
+    for (size_t i = 0; i < n_waves; ++i) {
+      tot += (double)hv[4 * i];
+      st += (double)hv[4 * i + 1];
+      br += (double)hv[4 * i + 2];
+    }
+    const double ntl = (double)hv[3];
+    fprintf(stderr, "[anirec topk stamps] last super-step: %d tiles; per wave per tile: total %.0f cycles, "
+            "vmcnt wait %.0f, barrier %.0f\n", (int)ntl, tot / n_waves / ntl, st / n_waves / ntl,
+            br / n_waves / ntl);
+  }
+  return ANIREC_OK;
+}
 
 extern "C" {
 
@@ -603,91 +772,11 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
     ANIREC_HIP_CHECK(hipMalloc((void **)&stamps, n_waves * 32));
     ca.dbg = stamps;
   }
-  // Super-steps of the key stream: thresholds are fixed inside a launch and refreshed between
-  // launches; each super-step doubles the number of keys seen, so a row gains about k_eff new
-  // candidates per super-step (the first one, with no threshold yet, must fit the buffer).
-  const int ntiles = (n + kBN - 1) / kBN;
-  // 256-row workgroups once they give every CU one (8 waves per CU either way); 128-row otherwise
-  const char *wv = getenv("ANIREC_TOPK_WAVES");
-  const bool wide = wv ? atoi(wv) == 8 : nq >= 49152;
-  const dim3 grid(wide ? (nq + 255) / 256 : (nq + 127) / 128);
-  const dim3 block(wide ? 512 : 256);
-  int n_launch = 0;
-  std::vector<hipEvent_t> timed;  // event pairs around the k_cand launches (timing mode only)
-  const char *gp = getenv("ANIREC_TOPK_GROWTH");
-  const int growth_pct = gp ? atoi(gp) : 100;
-  for (int t0 = 0, step = (kCap - kBN) / kBN; t0 < ntiles;) {
-    const int t1 = t0 + step < ntiles ? t0 + step : ntiles;
-    ca.tile0 = t0;
-    ca.tile1 = t1;
-#define ANIREC_LAUNCH_CAND(D)                                              \
-  do {                                                                     \
-    if (wide)                                                              \
-      hipLaunchKernelGGL((k_cand<D, 8>), grid, block, 0, s, ca);           \
-    else                                                                   \
-      hipLaunchKernelGGL((k_cand<D, 4>), grid, block, 0, s, ca);           \
-  } while (0)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (g_time_cand) {
-      ANIREC_HIP_CHECK(hipEventCreate(&ev0));
-      ANIREC_HIP_CHECK(hipEventCreate(&ev1));
-      ANIREC_HIP_CHECK(hipEventRecord(ev0, s));
-    }
-    if (mode == 1)
-      ANIREC_LAUNCH_CAND(1);
-    else if (mode == 2)
-      ANIREC_LAUNCH_CAND(2);
-    else if (mode == 4)
-      ANIREC_LAUNCH_CAND(4);
-    else
-      ANIREC_LAUNCH_CAND(0);
-#undef ANIREC_LAUNCH_CAND
-    if (g_time_cand) {
-      ANIREC_HIP_CHECK(hipEventRecord(ev1, s));
-      timed.push_back(ev0);
-      timed.push_back(ev1);
-    }
-    if (t1 < ntiles) hipLaunchKernelGGL(k_refresh, dim3(nq), dim3(64), 0, s, ca);
-    ANIREC_HIP_CHECK(hipGetLastError());
-    step = (int)((long long)t1 * growth_pct / 100);  // next super-step: growth_pct % of the tiles seen so far
-    if (step < 1) step = 1;
-    t0 = t1;
-    ++n_launch;
-  }
-  if (g_time_cand) {  // blocking: only bench.py's roofline leg arms this
-    g_cand_ms = 0.f;
-    g_cand_launches = (int)timed.size() / 2;
-    for (size_t i = 0; i + 1 < timed.size(); i += 2) {
-      float ms = 0.f;
-      (void)hipEventSynchronize(timed[i + 1]);
-      (void)hipEventElapsedTime(&ms, timed[i], timed[i + 1]);
-      g_cand_ms += ms;
-      (void)hipEventDestroy(timed[i]);
-      (void)hipEventDestroy(timed[i + 1]);
-    }
-  }
-  if (mode == 2) {
-    unsigned long long hv[2] = {0, 0};
-    (void)hipMemcpyAsync(hv, p, 16, hipMemcpyDeviceToHost, s);
-    (void)hipStreamSynchronize(s);
-    fprintf(stderr, "[anirec topk debug] nq=%d n=%d appends/row=%.1f super-steps=%d\n", nq, n,
-            (double)hv[0] / nq, n_launch);
-  }
-  if (mode == 4) {  // stamps of the LAST super-step
-    std::vector<unsigned long long> hv(n_waves * 4);
-    (void)hipStreamSynchronize(s);
-    (void)hipMemcpy(hv.data(), stamps, n_waves * 32, hipMemcpyDeviceToHost);
-    (void)hipFree(stamps);
-    double tot = 0, st = 0, br = 0;
-    for (size_t i = 0; i < n_waves; ++i) {
-      tot += (double)hv[4 * i];
-      st += (double)hv[4 * i + 1];
-      br += (double)hv[4 * i + 2];
-    }
-    const double ntl = (double)hv[3];
-    fprintf(stderr, "[anirec topk stamps] last super-step: %d tiles; per wave per tile: total %.0f cycles, "
-            "vmcnt wait %.0f, barrier %.0f\n", (int)ntl, tot / n_waves / ntl, st / n_waves / ntl,
-            br / n_waves / ntl);
+  ca.watched = nullptr;
+  ca.wwords = 0;
+  {
+    const int rc = run_super_steps(ca, n, nq, false, mode, p, stamps, n_waves, s);
+    if (rc) return rc;
   }
   RerankArgs ra;
   ra.What = What;
@@ -705,7 +794,101 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
   ra.out_idx = out_idx;
   ra.out_score = out_score;
   // self exclusion is by key index; without it the query index is only used to fetch the row
-  hipLaunchKernelGGL(k_rerank, dim3(nq), dim3(64), 0, s, ra);
+  ra.hs = ra.hb = 0.f;
+  ra.sign = 1.f;
+  hipLaunchKernelGGL(k_rerank<false>, dim3(nq), dim3(64), 0, s, ra);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// model_recs batched: top-k unwatched anime by predicted rating for many users, on the matrix cores.
+// ------------------------------------------------------------------------------------------------
+// Ah (n_anime fp32 rows) | Uh (n_users fp32 rows) | Wb | Qb | cand | cnt | theta
+size_t anirec_predict_topk_mfma_workspace_bytes(int32_t n_anime, int32_t n_users) {
+  if (n_anime < 1 || n_users < 1) return 0;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  return al((size_t)n_anime * 512) + al((size_t)n_users * 512) + al(padded_keys(n_anime) * 256) +
+         al((size_t)n_users * 256) + al((size_t)n_users * kCap * 8) + 2 * al((size_t)n_users * 4) + 256;
+}
+
+int anirec_predict_topk_mfma(const float *U, const float *A, int32_t n_anime, const int32_t *users,
+                             int32_t n_users, const anirec_head *head, const uint32_t *watched, int32_t k,
+                             int32_t *out_idx, float *out_p, int32_t *flags_out, void *workspace,
+                             size_t workspace_bytes, void *stream) {
+  if (!U || !A || !users || !head || !out_idx || !out_p || !flags_out || !workspace) return ANIREC_EINVAL;
+  if (n_anime < 1 || n_users < 0 || k < 1 || k > ANIREC_MAX_TOPK - 1) return ANIREC_EINVAL;
+  if (n_users == 0) return ANIREC_OK;
+  if (workspace_bytes < anirec_predict_topk_mfma_workspace_bytes(n_anime, n_users)) return ANIREC_EWORKSPACE;
+  if ((size_t)n_users * kCap * 8 >= ((size_t)1 << 32)) return ANIREC_EINVAL;  // batch the users
+  hipStream_t s = (hipStream_t)stream;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  char *p = (char *)workspace;
+  float *Ah = (float *)p;
+  p += al((size_t)n_anime * 512);
+  float *Uh = (float *)p;
+  p += al((size_t)n_users * 512);
+  _Float16 *Wb = (_Float16 *)p;
+  p += al(padded_keys(n_anime) * 256);
+  _Float16 *Qb = (_Float16 *)p;
+  p += al((size_t)n_users * 256);
+  uint2 *cand = (uint2 *)p;
+  p += al((size_t)n_users * kCap * 8);
+  int32_t *cnt = (int32_t *)p;
+  p += al((size_t)n_users * 4);
+  float *theta = (float *)p;
+  // sigmoid(gamma*(w*c+b-mu)/sqrt(var+eps)+beta) = sigmoid(c*hs + hb), folded exactly as the exact path does
+  float hs, hb;
+  head_affine_f32(head, &hs, &hb);
+  const float sign = hs < 0.f ? -1.f : 1.f;
+  int b1 = (n_anime + 7) / 8, b2 = (n_users + 7) / 8;
+  if (b1 > 8192) b1 = 8192;
+  if (b2 > 8192) b2 = 8192;
+  hipLaunchKernelGGL(k_norm_f16, dim3(b1), dim3(256), 0, s, A, nullptr, n_anime, (int)padded_keys(n_anime), 1.0f, Ah, Wb);
+  hipLaunchKernelGGL(k_norm_f16, dim3(b2), dim3(256), 0, s, U, users, n_users, n_users, sign, Uh, Qb);
+  hipLaunchKernelGGL(k_init_rows, dim3((n_users + 255) / 256), dim3(256), 0, s, cnt, theta, flags_out, n_users);
+  ANIREC_HIP_CHECK(hipGetLastError());
+  CandArgs ca;
+  ca.Qb = (const uint4 *)Qb;
+  ca.Wb = (const uint4 *)Wb;
+  ca.nq = n_users;
+  ca.n = n_anime;
+  ca.k_eff = k;
+  ca.cand = cand;
+  ca.cnt = cnt;
+  ca.theta = theta;
+  ca.flags = flags_out;
+  ca.dbg = nullptr;
+  ca.watched = watched;
+  ca.wwords = (n_anime + 31) / 32;
+  const bool masked = watched != nullptr;
+  {
+    const int rc = run_super_steps(ca, n_anime, n_users, masked, 0, nullptr, nullptr, 0, s);
+    if (rc) return rc;
+  }
+  RerankArgs ra;
+  ra.What = Ah;
+  ra.Qf = Uh;
+  ra.qidx = nullptr;
+  ra.nq = n_users;
+  ra.n = n_anime;
+  ra.k = k;
+  ra.k_eff = k;
+  ra.exclude_self = 0;
+  ra.cand = cand;
+  ra.cnt = cnt;
+  ra.theta = theta;
+  ra.flags = flags_out;
+  ra.out_idx = out_idx;
+  ra.out_score = out_p;
+  ra.hs = hs;
+  ra.hb = hb;
+  ra.sign = sign;
+  // a zero / non-finite slope makes every rating equal (or NaN): nothing to rank on the MFMA side
+  if (!(hs != 0.f) || !(hs == hs) || !(hb == hb)) {
+    hipLaunchKernelGGL(k_flag_all, dim3((n_users + 255) / 256), dim3(256), 0, s, flags_out, n_users, out_idx, out_p, k);
+    return (int)hipGetLastError();
+  }
+  hipLaunchKernelGGL(k_rerank<true>, dim3(n_users), dim3(64), 0, s, ra);
   return (int)hipGetLastError();
 }
 

@@ -212,6 +212,46 @@ def predict_topk(U, A, head, users, k, watched_bits=None):
     return out_i, out_p
 
 
+def predict_topk_mfma(U, A, head, users, k, watched_bits=None, batch=131072, fallback=True):
+    """predict_topk on the matrix cores (the batched model_recs path).  Users whose candidate window
+    could not be proven complete are transparently re-run through the exact kernels.
+    Returns (idx, p, n_fallback)."""
+    _need_gpu()
+    lib = _lib.load()
+    dev = U.device
+    us = _i32(users, dev)
+    n_a, n_q = A.shape[0], int(us.numel())
+    if not (1 <= k <= MAX_TOPK - 1):
+        raise ValueError("k must be in 1..%d" % (MAX_TOPK - 1))
+    out_i = torch.empty(n_q, k, dtype=torch.int32, device=dev)
+    out_p = torch.empty(n_q, k, dtype=torch.float32, device=dev)
+    if n_q == 0:
+        return out_i, out_p, 0
+    wb = None
+    if watched_bits is not None:
+        wb = torch.as_tensor(watched_bits, device=dev).to(torch.int32).contiguous()
+        assert wb.shape == (n_q, (n_a + 31) // 32)
+    h = _head_struct(head)
+    bq = min(n_q, int(batch))
+    ws = torch.empty(int(lib.anirec_predict_topk_mfma_workspace_bytes(n_a, bq)), dtype=torch.uint8, device=dev)
+    flags = torch.empty(bq, dtype=torch.int32, device=dev)
+    n_fb = 0
+    for q0 in range(0, n_q, bq):
+        cnt = min(bq, n_q - q0)
+        wq = wb[q0:q0 + cnt] if wb is not None else None
+        _lib.check(lib.anirec_predict_topk_mfma(_lib.ptr(U), _lib.ptr(A), n_a, _lib.ptr(us[q0:q0 + cnt]), cnt,
+                                                C.byref(h), _lib.ptr(wq), int(k), _lib.ptr(out_i[q0:q0 + cnt]),
+                                                _lib.ptr(out_p[q0:q0 + cnt]), _lib.ptr(flags), _lib.ptr(ws),
+                                                ws.numel(), _stream()), "anirec_predict_topk_mfma")
+        bad = torch.nonzero(flags[:cnt], as_tuple=False).flatten()
+        n_fb += int(bad.numel())
+        if bad.numel() and fallback:
+            fi, fp = predict_topk(U, A, head, us[q0:q0 + cnt][bad], k, wq[bad] if wq is not None else None)
+            out_i[q0 + bad] = fi
+            out_p[q0 + bad] = fp
+    return out_i, out_p, n_fb
+
+
 def adam_flat(w, m, v, g, alpha):
     """In-place Keras-2.12 Adam dense update of flat fp32 tensors (bit-exact vs the oracle)."""
     _need_gpu()

@@ -259,6 +259,18 @@ int anirec_predict_topk(const float *U, const float *A, int32_t n_anime, const i
                         int32_t k, int32_t *out_idx, float *out_p, void *workspace,
                         size_t workspace_bytes, void *stream);
 
+/* The same top-k on the matrix cores (the batched model_recs path: 100 k users x 18 k anime):
+ * fp16 MFMA cosine candidates with a rigorous error window, the watched mask applied when a
+ * candidate is appended, exact fp32 re-rank through the head.  Same results as
+ * anirec_predict_topk; flags[n_users] (device) is non-zero for the rare user whose window could
+ * not be proven complete (saturated head, > 256 survivors, fewer than k unwatched anime): its row
+ * is -1/NaN and the caller re-runs it through anirec_predict_topk.  k <= ANIREC_MAX_TOPK - 1. */
+size_t anirec_predict_topk_mfma_workspace_bytes(int32_t n_anime, int32_t n_users);
+int anirec_predict_topk_mfma(const float *U, const float *A, int32_t n_anime, const int32_t *users,
+                             int32_t n_users, const anirec_head *head_host, const uint32_t *watched,
+                             int32_t k, int32_t *out_idx, float *out_p, int32_t *flags, void *workspace,
+                             size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------- *
  *  INGEST — the step before the hot path, columns resident in HBM.
  *  Replaces preprocess/preprocess.py:13-40 (drop_useless: drop_duplicates keep-first, dropna,

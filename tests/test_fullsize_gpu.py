@@ -86,3 +86,29 @@ def test_predict_grid_full_anime_table_matches_pairwise_kernel():
     ju, ja = rng.integers(0, 2048, 20000), rng.integers(0, N_ANIME, 20000)
     p = ops.predict_pairs(U, A, head, users[torch.from_numpy(ju).cuda()], ja)
     np.testing.assert_allclose(G.cpu().numpy()[ju, ja], p.cpu().numpy(), atol=3e-6)
+
+
+def test_predict_topk_mfma_c5_sample_equals_exact_path():
+    """BASELINE C5 (100 k users x 18 k anime, ~25 % watched): the MFMA path on all users, the exact
+    kernels on a sample of them — identical lists; hardly any fallback."""
+    from anime_recommendations_amd import ops
+    n_u, n_a, nq, k = 350_000, 18_000, 100_000, 10
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    U = torch.randn(n_u, 128, generator=g, device="cuda") * 0.05
+    A = torch.randn(n_a, 128, generator=g, device="cuda") * 0.05
+    head = dict(w=1.3, b=0.1, gamma=0.9, beta=-0.2, mov_mean=0.05, mov_var=0.4)
+    users = torch.arange(nq, dtype=torch.int32, device="cuda")
+    shape = (nq, (n_a + 31) // 32)
+    watched = torch.randint(-2 ** 31, 2 ** 31 - 1, shape, generator=g, device="cuda", dtype=torch.int64).to(torch.int32)
+    watched &= torch.randint(-2 ** 31, 2 ** 31 - 1, shape, generator=g, device="cuda", dtype=torch.int64).to(torch.int32)
+    mi, mp, nfb = ops.predict_topk_mfma(U, A, head, users, k, watched)
+    assert nfb <= nq // 1000
+    sample = torch.arange(0, nq, 97, device="cuda")
+    ei, ep = ops.predict_topk(U, A, head, users[sample], k, watched[sample])
+    assert torch.equal(mi[sample], ei) and torch.equal(mp[sample], ep)
+    # every recommended anime is unwatched, ratings are sorted
+    idx = mi.long()
+    bit = (watched.gather(1, idx >> 5) >> (idx & 31)) & 1
+    assert int(bit.sum()) == 0
+    assert bool((mp[:, 1:] <= mp[:, :-1]).all())

@@ -178,3 +178,50 @@ def test_predict_grid_mfma_within_1e5_of_oracle_and_fp32_path():
     np.testing.assert_allclose(G, Gf, atol=3e-6)
     Go = orc.predict_grid(U, A, orc.new_head(**head), users[:40])
     np.testing.assert_allclose(G[:40], Go, atol=1e-5)      # BASELINE bar
+
+
+def _watched_bits(rng, nq, n_a, frac):
+    w = rng.random((nq, n_a)) < frac
+    bits = np.zeros((nq, (n_a + 31) // 32), np.uint32)
+    for a in range(n_a):
+        bits[:, a >> 5] |= (w[:, a].astype(np.uint32) << np.uint32(a & 31))
+    return w, bits.view(np.int32)
+
+
+@pytest.mark.parametrize("head_kw,expect_fallback", [
+    (dict(w=1.3, b=0.1, gamma=0.9, beta=-0.2, mov_mean=0.05, mov_var=0.4), False),
+    (dict(w=-2.0, b=0.3, gamma=1.1, beta=0.1, mov_mean=-0.02, mov_var=0.9), False),   # negative slope: ranks reversed
+    (dict(w=400.0, b=0.0, gamma=1.0, beta=30.0, mov_mean=0.0, mov_var=1.0), True),     # saturated sigmoid: ties -> fallback
+    (dict(w=0.0, b=0.3, gamma=1.0, beta=0.1, mov_mean=0.0, mov_var=1.0), True),        # zero slope: every rating equal
+])
+def test_predict_topk_mfma_equals_exact_path_bitwise(head_kw, expect_fallback):
+    """model_recs batched: MFMA candidates + watched mask + exact re-rank == exact kernels, bit for bit."""
+    from anime_recommendations_amd import ops
+    rng = np.random.default_rng(31)
+    n_u, n_a, nq, k = 900, 3000, 600, 10
+    U = torch.from_numpy(rng.normal(0, 0.05, (n_u, 128)).astype(np.float32)).cuda()
+    A = rng.normal(0, 0.05, (n_a, 128)).astype(np.float32)
+    A[7] = A[3]                                   # exact rating ties between anime
+    A[9] = 0                                      # zero row: tf l2_normalize gives 0, cosine 0
+    A = torch.from_numpy(A).cuda()
+    users = rng.permutation(n_u)[:nq].astype(np.int32)
+    w, bits = _watched_bits(rng, nq, n_a, 0.3)
+    bits_few = bits.copy()
+    bits_few[5] = -1                              # user 5 has watched everything: fewer than k candidates
+    bits_few[6, :-1] = -1                         # user 6 has 24 unwatched anime at most
+    for wb in (None, bits, bits_few):
+        ei, ep = ops.predict_topk(U, A, head_kw, users, k, wb)
+        mi, mp, nfb = ops.predict_topk_mfma(U, A, head_kw, users, k, wb)
+        ei, ep, mi, mp = (x.cpu().numpy() for x in (ei, ep, mi, mp))
+        assert (mi == ei).all()
+        assert (mp == ep)[~np.isnan(ep)].all() and (np.isnan(mp) == np.isnan(ep)).all()
+        if expect_fallback:
+            assert nfb > nq // 2
+        else:
+            assert nfb <= (4 if wb is bits_few else 2)
+    # without the fallback the flagged rows are -1 / NaN, never wrong
+    mi2, mp2, _ = ops.predict_topk_mfma(U, A, head_kw, users, k, bits, fallback=False)
+    mi2 = mi2.cpu().numpy()
+    ei, _ = ops.predict_topk(U, A, head_kw, users, k, bits)
+    ok = mi2[:, 0] >= 0
+    assert (mi2[ok] == ei.cpu().numpy()[ok]).all()
