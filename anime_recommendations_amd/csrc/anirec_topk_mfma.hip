@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64) void k_refresh(CandArgs a) {
 // kWaves = 8 (256 query rows per workgroup, one workgroup per CU) halves the L2 -> LDS key traffic per
 // MFMA and is used when the queries fill the chip that way; kWaves = 4 (two workgroups per CU) otherwise.
 // kMask: a candidate is dropped at append time when its bit in the query's own mask row is set (the
-// "already watched" set of model_recs); one extra load on the rare append path, nothing in the MFMA loop.
+// "already watched" set of model_recs); the mask words are prefetched a tile ahead into registers.
 template <int kDbg, int kWaves, bool kMask = false>  // kDbg 0: product; 1: no filter (timing only); 2: count appends; 4: stamps
 __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
   constexpr int kBM = 32 * kWaves;
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
   auto mma1 = [&](Acc &x, int rb, int nb, int kk) {
     x.c[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[rb][kk], bv[nb][kk], kk == 0 ? nthr[rb] : x.c[rb][nb], 0, 0, 0);
   };
-  auto stage_fn = [&](const Acc &cur, Acc &nxt, int key0, int fbuf, int fcb) {
+  auto stage_fn = [&](const Acc &cur, Acc &nxt, int key0, int fbuf, int fcb, uint32_t mword) {
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {  // quarter qd: MFMA step kk = qd of the next block, filter (rb, nb) of this one
       const int rb = qd >> 1, nb = qd & 1;
@@ -342,9 +342,9 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           bool hit = cv[i] >= 0.f;
-          if (kMask && hit) {  // dead rows (C-in = -inf) never get here: the mask row exists
-            const size_t rl = (size_t)(q0 + 32 * w + 16 * rb + 4 * gq + i);
-            hit = ((a.watched[rl * a.wwords + (key >> 5)] >> (key & 31)) & 1u) == 0u;
+          if (kMask) {  // the row's 32 mask bits of this key block sit in lane (row) of the prefetched word
+            const uint32_t wbits = (uint32_t)__shfl((int)mword, 16 * rb + 4 * gq + i, 64);
+            hit = hit && ((wbits >> (16 * nb + c16)) & 1u) == 0u;
           }
           const unsigned long long mk = __ballot(hit);
           if (mk) {  // wave-uniform
@@ -370,13 +370,31 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) fetch(kk, 0, 1);
 
+  // kMask: lane l < 32 holds the four 32-key mask words of query row l of the wave for the current
+  // tile (one 16-B load per row and tile, prefetched a tile ahead), so the append path tests a bit
+  // after one cross-lane read instead of a dependent global load.
+  u32x4 mcur = {0u, 0u, 0u, 0u}, mnext = {0u, 0u, 0u, 0u};
+  auto load_mask = [&](int t) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    const int rl = q0 + 32 * w + (lane & 31);
+    if (rl < a.nq) {
+      const uint32_t *src = a.watched + (size_t)rl * a.wwords;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int wd = t * (kBN / 32) + j;
+        if (wd < a.wwords) v[j] = src[wd];
+      }
+    }
+    return v;
+  };
+  if (kMask) mcur = load_mask(a.tile0);
   unsigned long long dbg_store = 0, dbg_barrier = 0, dbg_t0 = 0;
   if (kDbg == 4) dbg_t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < nt; ++it) {
     const int buf = it & 1;
     const int key0 = (a.tile0 + it) * kBN;
-    stage_fn(acc0, acc1, key0, buf, 2);       // filter block 0 | MFMA block 1 | fetch block 2
-    stage_fn(acc1, acc0, key0 + 32, buf, 3);  // filter block 1 | MFMA block 2 | fetch block 3
+    stage_fn(acc0, acc1, key0, buf, 2, mcur[0]);       // filter block 0 | MFMA block 1 | fetch block 2
+    stage_fn(acc1, acc0, key0 + 32, buf, 3, mcur[1]);  // filter block 1 | MFMA block 2 | fetch block 3
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
     if (kDbg == 4) ts0 = __builtin_amdgcn_s_memtime();
     // tile it+1 was sent to the other buffer one tile ago; its DMA (and this wave's candidate stores,
@@ -394,10 +412,12 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
     }
     // this tile's buffer was last read (fetched) before the barrier: refill it with tile it+2, in
     // flight for a whole tile
+    if (kMask && it + 1 < nt) mnext = load_mask(a.tile0 + it + 1);
     if (it + 2 < nt) dma_tile(a.tile0 + it + 2, buf);
     // on the last tile the "next tile" blocks are stale LDS: computed and thrown away
-    stage_fn(acc0, acc1, key0 + 64, buf ^ 1, 0);  // filter block 2 | MFMA block 3 | fetch next tile's block 0
-    stage_fn(acc1, acc0, key0 + 96, buf ^ 1, 1);  // filter block 3 | MFMA next block 0 | fetch next block 1
+    stage_fn(acc0, acc1, key0 + 64, buf ^ 1, 0, mcur[2]);  // filter block 2 | MFMA block 3 | fetch next tile's block 0
+    stage_fn(acc1, acc0, key0 + 96, buf ^ 1, 1, mcur[3]);  // filter block 3 | MFMA next block 0 | fetch next block 1
+    if (kMask) mcur = mnext;
   }
   if (kDbg == 4 && lane == 0) {  // in-kernel stamps (diagnostic build only): cycles per wave
     unsigned long long *d = a.dbg + 4 * (size_t)(blockIdx.x * kWaves + w);
@@ -623,7 +643,12 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
   std::vector<hipEvent_t> timed;  // event pairs around the k_cand launches (timing mode only)
   const char *gp = getenv("ANIREC_TOPK_GROWTH");
   const int growth_pct = gp ? atoi(gp) : 100;
-  for (int t0 = 0, step = (kCap - kBN) / kBN; t0 < ntiles;) {
+  // the first super-step runs without a threshold and appends every key it sees: keep it as short as
+  // the k-th-best estimate allows (>= 4 k_eff keys), at most what the buffer holds
+  int first = (4 * ca.k_eff + kBN - 1) / kBN;
+  if (first > (kCap - kBN) / kBN) first = (kCap - kBN) / kBN;
+  if (first < 1) first = 1;
+  for (int t0 = 0, step = first; t0 < ntiles;) {
     const int t1 = t0 + step < ntiles ? t0 + step : ntiles;
     ca.tile0 = t0;
     ca.tile1 = t1;
