@@ -45,12 +45,13 @@ def sharded_cosine_topk(What, k, exclude_self=True, keep=None, topk_fn=None):
 def sharded_predict_topk(U, A, head, users, k, watched_bits=None, predict_fn=None):
     """Top-k unwatched anime for every listed user, users sharded across ranks."""
     if predict_fn is None:
-        from .ops import predict_topk as predict_fn
+        from .ops import predict_topk_mfma as predict_fn     # matrix cores; exact kernels for flagged users
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     users = torch.as_tensor(users, device=U.device)
     n = users.numel()
     lo, hi = shard_bounds(n, rank, world)
     wb = None if watched_bits is None else torch.as_tensor(watched_bits, device=U.device)[lo:hi]
-    idx, p = predict_fn(U, A, head, users[lo:hi], k, wb)
+    res = predict_fn(U, A, head, users[lo:hi], k, wb)
+    idx, p = res[0], res[1]
     return gather_rows(idx, n, world, rank), gather_rows(p, n, world, rank)
