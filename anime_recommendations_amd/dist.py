@@ -17,6 +17,8 @@ Per step: fwd -> all_gather(packets) -> head -> bwd -> all_reduce(anime grad) ->
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -74,7 +76,8 @@ class DistTrainEngine:
             from .engine import TrainEngine as engine_factory
         self.eng = engine_factory(self.n_local, self.n_anime, max_batch=max_batch, l2=l2,
                                   arena_steps=arena_steps, device=device, n_seg=self.world,
-                                  my_seg=self.rank, anime_dense=self.world > 1)
+                                  my_seg=self.rank,
+                                  anime_dense=self.world > 1 or os.environ.get("ANIREC_DIST_LOOP") == "1")
         self.device = self.eng.device
         self.l2 = float(l2)
         self.cursor = 0
@@ -146,7 +149,7 @@ class DistTrainEngine:
             first_step = self.cursor
         if n_steps is None:
             n_steps = e.n_steps - first_step
-        if self.world == 1:
+        if self.world == 1 and os.environ.get("ANIREC_DIST_LOOP") != "1":   # (=1: rehearse the N>1 loop on one rank)
             e.run(n_steps, use_graph=use_graph, first_step=first_step)
             self.cursor = first_step + n_steps
             return n_steps
