@@ -137,3 +137,31 @@ def encode_columns(cols, shuffle=True, random_state=42) -> EncodedRatings:
         ui, ai = ui[perm], ai[perm]
         r = r[perm]
     return EncodedRatings(ui, ai, r, user_ids, anime_ids)
+
+
+def encode_frame(df, shuffle=True, random_state=42, min_ratings=None, device="cuda:0"):
+    """``data.encode_frame`` (the reference's get_df) with the id encoding done on the GPU; returns the
+    same ``data.RatingTable`` of NumPy columns (int64 indices, float64 ratings), value for value."""
+    from . import data
+    if min_ratings:
+        n_ratings = df["user_id"].value_counts(dropna=True)
+        df = df[df["user_id"].isin(n_ratings[n_ratings >= int(min_ratings)].index)]
+    ids = {}
+    for name in ("user_id", "anime_id"):
+        col = df[name].to_numpy()
+        if col.dtype.kind != "i" or (col.size and (col.max() >= 2 ** 31 or col.min() < 0)):
+            return data.encode_frame(df, shuffle=shuffle, random_state=random_state)   # ids that are not int32 >= 0
+        ids[name] = torch.as_tensor(col.astype(np.int32), device=device)
+    ui, user_ids = encode_ids(ids["user_id"])
+    ai, anime_ids = encode_ids(ids["anime_id"])
+    u, a = ui.cpu().numpy().astype(np.int64), ai.cpu().numpy().astype(np.int64)
+    r = df["rating"].to_numpy()
+    if shuffle:
+        order = data.shuffle_order(len(df), random_state)
+        u, a, r = u[order], a[order], r[order]
+    return data.RatingTable(u, a, r, user_ids.cpu().numpy().astype(col.dtype), anime_ids.cpu().numpy().astype(col.dtype))
+
+
+def load_user_stats(path, **kw):
+    import pandas as pd
+    return encode_frame(pd.read_parquet(path), **kw)

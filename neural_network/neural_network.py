@@ -28,7 +28,7 @@ logger = C.setup_logging("neural_network")
 
 
 def go(args):
-    from anime_recommendations_amd import data, trainer, weights_io
+    from anime_recommendations_amd import data, ingest, trainer, weights_io
     # the graph is fixed by the kernels: reject configurations they do not implement
     for flag, want in (("model_loss", "binary_crossentropy"), ("optimizer", "adam"),
                        ("activation_function", "sigmoid"), ("kernel_initializer", "he_normal")):
@@ -38,7 +38,8 @@ def go(args):
     if args.TPU_INIT:
         logger.info("TPU_INIT requested: ignored, training runs on MI355X (use torchrun for >1 GPU)")
     logger.info("Loading data artifact %s", args.input_data)
-    table = data.load_user_stats(artifacts.use_artifact(args.input_data, args.main_df_type))
+    # get_df (neural_network.py:25-63 of the reference): the id encoding runs on the GPU (ingest.py)
+    table = ingest.load_user_stats(artifacts.use_artifact(args.input_data, args.main_df_type))
     logger.info("Final df shape is (%d, 3); %d users, %d anime", len(table), table.n_users, table.n_anime)
     cfg = trainer.FitConfig(
         epochs=int(args.epochs), batch_size=int(args.batch_size), test_size=int(args.test_size),

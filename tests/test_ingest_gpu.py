@@ -149,3 +149,15 @@ def test_fullsize_properties_109m_rows():
     first = torch.full((int(uniq.numel()),), m, dtype=torch.int64, device="cuda")
     first.scatter_reduce_(0, idx.long(), torch.arange(m, device="cuda"), reduce="amin")
     assert bool((first[1:] > first[:-1]).all())
+
+
+def test_encode_frame_gpu_equals_host_encode_frame():
+    """The RatingTable the neural_network component trains on: GPU id encoding == data.encode_frame."""
+    from anime_recommendations_amd import data, ingest
+    df = data.synth_user_stats(n_users=400, n_anime=300, n_ratings=30_000, seed=5)
+    for kw in (dict(), dict(shuffle=False), dict(min_ratings=60)):
+        ref = data.encode_frame(df, **kw)
+        got = ingest.encode_frame(df, **kw)
+        for f in ("user", "anime", "rating", "user_ids", "anime_ids"):
+            a, b = getattr(got, f), getattr(ref, f)
+            assert a.dtype == b.dtype and np.array_equal(a, b), f
