@@ -151,6 +151,11 @@ def run_single(workload, steps, warmup, batch, use_graph=True, cpu_baseline=True
                      "frac": adam_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": adam_bytes,
                      "avg_launch_ms": kern_ms["adam"]},
+        # whole-step roofline of SURVEY.md §8(d): (3.1 KB x B + 28 B x table elements) / step time
+        "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_step": (FWD_BYTES_PER_RATING + BWD_BYTES_PER_RATING) * batch + adam_bytes,
+                          "achieved": ((FWD_BYTES_PER_RATING + BWD_BYTES_PER_RATING) * batch + adam_bytes) / (dt / steps) / 1e9,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": ((FWD_BYTES_PER_RATING + BWD_BYTES_PER_RATING) * batch + adam_bytes) / (dt / steps) / 1e9 / HBM_PEAK_GBS},
         "fwd_gbs": FWD_BYTES_PER_RATING * batch / (kern_ms["fwd"] * 1e-3) / 1e9,
         "bwd_gbs": BWD_BYTES_PER_RATING * batch / (kern_ms["bwd"] * 1e-3) / 1e9,
     }
@@ -461,6 +466,7 @@ def main():
                                "L2 1e-4, Keras-2.12 Adam, lr=lrfn(0)=1e-5" % (args.workload, n_users, n_anime, args.batch),
                    "global_batch": args.batch, "parallelism": "dp1"},
         "roofline": res["roofline"],
+        "step_roofline": res["step_roofline"],
         "cpu_baseline": res.get("cpu_baseline"),
         "kernels_ms": res["kernels_ms"],
         "embed_fwd_GBps": res["fwd_gbs"], "embed_bwd_GBps": res["bwd_gbs"],
