@@ -231,12 +231,19 @@ def run_cosine_topk(cpu_baseline=True):
         ops.cosine_topk_mfma(Wh, q, k)
         cand_ms, cand_launches = ops.topk_mfma_timing(False)
         tfk = flops / (cand_ms * 1e-3) / 1e12
+        traffic = None      # HBM bytes of the k_cand launches of one call, from the PMC passes under profiles/
+        try:
+            if (n, nq, k) == (350_000, 65_536, 10):
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_cosine_topk_350k_x_65536_k10.json")))[
+                    "hbm_traffic_k_cand_all_13_launches"]["total_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
         rec = {"value": nq / dt, "unit": "queries/s", "ms": dt * 1e3, "k": k, "fallback_rows": int(nfb),
                "pipeline_tflops": tf,
                "roofline": {"kernel": "k_cand (v_mfma_f32_16x16x32_f16 scores + fused candidate filter), "
                                       "%d super-step launches summed" % cand_launches,
                             "bound": "mfma", "achieved": tfk, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": tfk / MFMA_F16_PEAK_TFLOPS, "kernel_ms": cand_ms, "traffic": None}}
+                            "frac": tfk / MFMA_F16_PEAK_TFLOPS, "kernel_ms": cand_ms, "traffic": traffic}}
         if cpu_baseline and k == 10:
             from oracle import c_oracle
             Whn = Wh.cpu().numpy()
