@@ -1176,6 +1176,17 @@ static AdamArgs adam_args(const anirec_train_desc *d, const TrainWs &w) {
   return a;
 }
 
+// Grid of every k_adam launch of a descriptor (init, whole step, user part, anime part): a function of
+// the table size only, so the same regpart entries are rewritten each step.  Two rows per half-wave at
+// least, so the two-rows-in-flight pipeline has something to overlap on small (cache-resident) tables.
+static inline int adam_grid(const anirec_train_desc *d) {
+  const long long rows = (long long)d->n_user_rows + d->n_anime_rows;
+  long long b = (rows + 15) / 16;
+  if (b < 64) b = 64;
+  if (b > ANIREC_ADAM_BLOCKS) b = ANIREC_ADAM_BLOCKS;
+  return (int)b;
+}
+
 // which: 0 = every row (one launch), 1 = user rows only (may run while the anime gradient is
 // still being all-reduced), 2 = anime rows only + finish the step
 static int launch_adam(const anirec_train_desc *d, const TrainWs &w, hipStream_t s, int which = 0) {
@@ -1191,9 +1202,9 @@ static int launch_adam(const anirec_train_desc *d, const TrainWs &w, hipStream_t
   // (the 7M-rating shape: 50 MB of W+M+V) stay cache-resident between steps
   const size_t table_bytes = (size_t)a.n_rows * kDim * 4 * 3;
   if (table_bytes > ((size_t)192 << 20))
-    hipLaunchKernelGGL((k_adam<true, true>), dim3(ANIREC_ADAM_BLOCKS), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_adam<true, true>), dim3(adam_grid(d)), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((k_adam<true, false>), dim3(ANIREC_ADAM_BLOCKS), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_adam<true, false>), dim3(adam_grid(d)), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
 
@@ -1217,7 +1228,9 @@ int anirec_train_init_reg(const anirec_train_desc *d, void *stream) {
   TrainWs w = carve(d->workspace, d->max_batch, d->arena_steps);
   AdamArgs a = adam_args(d, w);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL((k_adam<false, false>), dim3(ANIREC_ADAM_BLOCKS), dim3(256), 0, s, a);
+  // entries beyond the grid are never written again: they must be (and stay) zero
+  ANIREC_HIP_CHECK(hipMemsetAsync(w.regpart, 0, sizeof(float) * 2 * ANIREC_ADAM_BLOCKS, s));
+  hipLaunchKernelGGL((k_adam<false, false>), dim3(adam_grid(d)), dim3(256), 0, s, a);
   ANIREC_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(k_sum_regpart, dim3(1), dim3(1024), 0, s, d->state, w.regpart);
   return (int)hipGetLastError();
