@@ -150,12 +150,15 @@ struct SelectArgs {
   const uint8_t *keep;   // optional [n] byte mask shared by all queries
   const uint32_t *wbits; // optional [nq][wwords] bit mask: set bit = excluded (watched)
   int wwords;
-  int32_t *out_idx;      // [nq][k]
-  float *out_score;      // [nq][k]
+  int32_t *out_idx;      // [nq * slices][k]
+  float *out_score;      // [nq * slices][k]
+  int slices, slice_len; // workgroup b selects among keys [s*slice_len, (s+1)*slice_len) of query b / slices
+  const int32_t *src_idx; // merge pass: [nq][ld] real index of list entry j (-1 = empty), masks already applied
 };
 
 __device__ __forceinline__ uint32_t cand_key(const SelectArgs &a, const float *row, int q, int j,
                                              int self) {
+  if (a.src_idx) return a.src_idx[(size_t)q * a.ld + j] < 0 ? 0u : score_key(row[j]);
   if (j == self) return 0u;
   if (a.keep && !a.keep[j]) return 0u;
   if (a.wbits && ((a.wbits[(size_t)q * a.wwords + (j >> 5)] >> (j & 31)) & 1u)) return 0u;
@@ -170,7 +173,14 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a) {
   __shared__ uint32_t wsum[kSelThreads / 64];
   __shared__ unsigned long long win[ANIREC_MAX_TOPK];  // (key << 32) | ~idx  -> sort desc
   const int tid = threadIdx.x;
-  const int q = blockIdx.x;
+  // Few queries (the reference's literal call is ONE query against every row): a query's keys are cut
+  // into slices, one workgroup each, and a second launch of this kernel merges the slice winners.  The
+  // winners of a slice are sorted (score desc, index asc) and slices cover ascending index ranges, so
+  // list order among equal scores is ascending index — the tie rule survives the merge unchanged.
+  const int q = blockIdx.x / a.slices;
+  const int j_lo = (blockIdx.x % a.slices) * a.slice_len;
+  const int j_hi = min(a.n, j_lo + a.slice_len);
+  const size_t orow = blockIdx.x;
   const float *row = a.scores + (size_t)q * a.ld;
   const int self = a.self ? a.self[q] : -1;
   const int k = a.k;
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a) {
     const int shift = 24 - 8 * pass;
     hist[tid] = 0;
     __syncthreads();
-    for (int j = tid; j < a.n; j += kSelThreads) {
+    for (int j = j_lo + tid; j < j_hi; j += kSelThreads) {
       const uint32_t key = cand_key(a, row, q, j, self);
       if (key != 0u && (key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
     }
@@ -222,14 +232,14 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a) {
   uint32_t eq_taken = 0;
   constexpr int kPer = 16;
   const int super = kSelThreads * kPer;
-  for (int base = 0; base < a.n; base += super) {
+  for (int base = j_lo; base < j_hi; base += super) {
     uint32_t keys[kPer];
     uint32_t c_gt = 0, c_eq = 0;
     const int j0 = base + tid * kPer;
 #pragma unroll
     for (int e = 0; e < kPer; ++e) {
       const int j = j0 + e;
-      keys[e] = j < a.n ? cand_key(a, row, q, j, self) : 0u;
+      keys[e] = j < j_hi ? cand_key(a, row, q, j, self) : 0u;
       if (keys[e] != 0u) {
         if (short_row || keys[e] > T) ++c_gt;
         else if (keys[e] == T) ++c_eq;
@@ -323,11 +333,11 @@ __global__ __launch_bounds__(kSelThreads) void k_select(SelectArgs a) {
     const unsigned long long v = win[i];
     if ((uint32_t)i < n_out && v != 0ull) {
       const int j = (int)(~(uint32_t)(v & 0xFFFFFFFFull));
-      a.out_idx[(size_t)q * k + i] = j;
-      a.out_score[(size_t)q * k + i] = row[j];
+      a.out_idx[orow * k + i] = a.src_idx ? a.src_idx[(size_t)q * a.ld + j] : j;
+      a.out_score[orow * k + i] = row[j];
     } else {
-      a.out_idx[(size_t)q * k + i] = -1;
-      a.out_score[(size_t)q * k + i] = __uint_as_float(0x7FC00000u);
+      a.out_idx[orow * k + i] = -1;
+      a.out_score[orow * k + i] = __uint_as_float(0x7FC00000u);
     }
   }
 }
@@ -359,6 +369,46 @@ __global__ void k_fill_self(const int32_t *queries, int nq, int32_t *self, int e
 }
 
 static inline void head_affine(const anirec_head *h, float *hs, float *hb) { head_affine_f32(h, hs, hb); }
+
+// scratch of the sliced select: at most kSelMaxBlocks slice winners lists of ANIREC_MAX_TOPK entries
+constexpr int kSelMaxBlocks = 2048;
+constexpr size_t kSelTmpBytes = (size_t)kSelMaxBlocks * ANIREC_MAX_TOPK * 8;
+
+// one launch when there are enough queries to fill the chip; otherwise slices + merge
+static int launch_select(SelectArgs sa, void *tmp, hipStream_t s) {
+  sa.src_idx = nullptr;
+  int S = 1;
+  if (sa.nq < 1024 && sa.n >= 4096) {
+    S = sa.n / 2048;
+    if (S > 64) S = 64;
+    if (S > kSelMaxBlocks / sa.nq) S = kSelMaxBlocks / sa.nq;
+    if (S < 1) S = 1;
+  }
+  sa.slices = S;
+  sa.slice_len = (sa.n + S - 1) / S;
+  if (S == 1) {
+    hipLaunchKernelGGL(k_select, dim3(sa.nq), dim3(kSelThreads), 0, s, sa);
+    return (int)hipGetLastError();
+  }
+  int32_t *tmp_idx = (int32_t *)tmp;
+  float *tmp_score = (float *)((char *)tmp + (size_t)kSelMaxBlocks * ANIREC_MAX_TOPK * 4);
+  SelectArgs part = sa;
+  part.out_idx = tmp_idx;
+  part.out_score = tmp_score;
+  hipLaunchKernelGGL(k_select, dim3(sa.nq * S), dim3(kSelThreads), 0, s, part);
+  SelectArgs m = sa;
+  m.scores = tmp_score;
+  m.src_idx = tmp_idx;
+  m.ld = (size_t)S * sa.k;
+  m.n = S * sa.k;
+  m.self = nullptr;
+  m.keep = nullptr;
+  m.wbits = nullptr;
+  m.slices = 1;
+  m.slice_len = m.n;
+  hipLaunchKernelGGL(k_select, dim3(sa.nq), dim3(kSelThreads), 0, s, m);
+  return (int)hipGetLastError();
+}
 
 static int launch_scores(const ScoreArgs &a, hipStream_t s) {
   dim3 grid((a.n + kTile - 1) / kTile, (a.nq + kTile - 1) / kTile);
@@ -404,7 +454,7 @@ size_t anirec_topk_workspace_bytes(int32_t n, int32_t nq) {
   size_t qb = (size_t)nq < 1024 ? (size_t)nq : 1024;
   // cap the score buffer at 4 GiB
   while (qb > 1 && qb * (size_t)n * 4 > ((size_t)4 << 30)) qb >>= 1;
-  return self_bytes + qb * (size_t)n * 4;
+  return self_bytes + kSelTmpBytes + qb * (size_t)n * 4;
 }
 
 int anirec_cosine_topk(const float *What, int32_t n, const int32_t *queries, int32_t nq,
@@ -415,10 +465,11 @@ int anirec_cosine_topk(const float *What, int32_t n, const int32_t *queries, int
   if (nq == 0) return ANIREC_OK;
   hipStream_t s = (hipStream_t)stream;
   size_t self_bytes = ((size_t)nq * 4 + 255) / 256 * 256;
-  if (workspace_bytes < self_bytes + (size_t)n * 4) return ANIREC_EWORKSPACE;
+  if (workspace_bytes < self_bytes + kSelTmpBytes + (size_t)n * 4) return ANIREC_EWORKSPACE;
   int32_t *self = (int32_t *)workspace;
-  float *buf = (float *)((char *)workspace + self_bytes);
-  size_t qb = (workspace_bytes - self_bytes) / ((size_t)n * 4);
+  void *sel_tmp = (char *)workspace + self_bytes;
+  float *buf = (float *)((char *)workspace + self_bytes + kSelTmpBytes);
+  size_t qb = (workspace_bytes - self_bytes - kSelTmpBytes) / ((size_t)n * 4);
   if (qb > (size_t)nq) qb = nq;
   hipLaunchKernelGGL(k_fill_self, dim3((nq + 255) / 256), dim3(256), 0, s, queries, nq, self,
                      exclude_self);
@@ -449,8 +500,8 @@ int anirec_cosine_topk(const float *What, int32_t n, const int32_t *queries, int
     sa.wwords = 0;
     sa.out_idx = out_idx + q0 * k;
     sa.out_score = out_score + q0 * k;
-    hipLaunchKernelGGL(k_select, dim3(cnt), dim3(kSelThreads), 0, s, sa);
-    ANIREC_HIP_CHECK(hipGetLastError());
+    e = launch_select(sa, sel_tmp, s);
+    if (e) return e;
   }
   return ANIREC_OK;
 }
@@ -478,7 +529,7 @@ size_t anirec_predict_workspace_bytes(int32_t n_anime, int32_t n_users, int32_t 
   size_t b = norm_bytes(n_anime, n_users);
   if (topk) {
     size_t qb = (size_t)n_users < 4096 ? (size_t)n_users : 4096;
-    b += qb * (size_t)n_anime * 4;
+    b += kSelTmpBytes + qb * (size_t)n_anime * 4;
   }
   return b;
 }
@@ -519,12 +570,13 @@ int anirec_predict_topk(const float *U, const float *A, int32_t n_anime, const i
   if (!U || !A || !users || !head || !out_idx || !out_p || !workspace) return ANIREC_EINVAL;
   if (n_anime < 1 || n_users < 0 || k < 1 || k > ANIREC_MAX_TOPK) return ANIREC_EINVAL;
   if (n_users == 0) return ANIREC_OK;
-  const size_t nb = norm_bytes(n_anime, n_users);
+  const size_t nb = norm_bytes(n_anime, n_users) + kSelTmpBytes;
   if (workspace_bytes < nb + (size_t)n_anime * 4) return ANIREC_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   float *Ah = (float *)workspace;
   float *Uh = Ah + (size_t)n_anime * kDim;
-  float *buf = Uh + (size_t)n_users * kDim;
+  void *sel_tmp = Uh + (size_t)n_users * kDim;
+  float *buf = (float *)((char *)sel_tmp + kSelTmpBytes);
   size_t qb = (workspace_bytes - nb) / ((size_t)n_anime * 4);
   if (qb > (size_t)n_users) qb = n_users;
   int b1 = (n_anime + 7) / 8, b2 = (n_users + 7) / 8;
@@ -563,8 +615,8 @@ int anirec_predict_topk(const float *U, const float *A, int32_t n_anime, const i
     sa.wwords = wwords;
     sa.out_idx = out_idx + q0 * k;
     sa.out_score = out_p + q0 * k;
-    hipLaunchKernelGGL(k_select, dim3(cnt), dim3(kSelThreads), 0, s, sa);
-    ANIREC_HIP_CHECK(hipGetLastError());
+    e = launch_select(sa, sel_tmp, s);
+    if (e) return e;
   }
   return ANIREC_OK;
 }

@@ -67,10 +67,16 @@ def cosine_topk(What, queries, k, exclude_self=True, keep=None, workspace=None):
         raise ValueError("k must be in 1..%d" % MAX_TOPK)
     dev = What.device
     n = What.shape[0]
-    q = _i32(queries, dev)
+    if not isinstance(queries, torch.Tensor) or not queries.is_cuda:
+        qh = np.asarray(queries if not isinstance(queries, torch.Tensor) else queries.numpy())
+        if qh.size and (qh.min() < 0 or qh.max() >= n):       # validated on the host: no device sync
+            raise ValueError("query row out of range")
+        q = _i32(qh, dev)
+    else:
+        q = _i32(queries, dev)
+        if q.numel() and bool(((q < 0) | (q >= n)).any()):     # one sync instead of two
+            raise ValueError("query row out of range")
     nq = int(q.numel())
-    if nq and (int(q.min()) < 0 or int(q.max()) >= n):
-        raise ValueError("query row out of range")
     out_i = torch.empty(nq, k, dtype=torch.int32, device=dev)
     out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
     if nq == 0:

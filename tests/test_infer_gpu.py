@@ -225,3 +225,32 @@ def test_predict_topk_mfma_equals_exact_path_bitwise(head_kw, expect_fallback):
     ei, _ = ops.predict_topk(U, A, head_kw, users, k, bits)
     ok = mi2[:, 0] >= 0
     assert (mi2[ok] == ei.cpu().numpy()[ok]).all()
+
+
+def test_cosine_topk_few_queries_sliced_select_keeps_the_tie_rule():
+    """Few queries against many keys (the reference's literal call is ONE query): the keys are cut into
+    slices selected by separate workgroups and merged — duplicates straddling slice boundaries, a key
+    mask, self exclusion and k = 128 must come out exactly as the single-workgroup rule says."""
+    from anime_recommendations_amd import ops
+    rng = np.random.default_rng(41)
+    n, k = 150_000, 128
+    W = rng.normal(0, 0.05, (n, 128)).astype(np.float32)
+    dup = [7, 2400, 2343, 2344, 70_000, 149_999]          # 150000/64 slices = 2344 keys each
+    for d in dup[1:]:
+        W[d] = W[dup[0]]
+    Wh = ops.rownorm(torch.from_numpy(W))
+    keep = rng.random(n) > 0.2
+    keep[dup] = True
+    keep[2343] = False
+    for queries in ([7], [2400, 5, 149_999]):
+        for kp in (None, keep):
+            idx, sim = ops.cosine_topk(Wh, queries, k, keep=None if kp is None else kp.astype(np.uint8))
+            idx, sim = idx.cpu().numpy(), sim.cpu().numpy()
+            for j, q in enumerate(queries):
+                s = ops.cosine_scores(Wh, q).cpu().numpy()
+                oi, os_ = orc.topk_desc(s, k, exclude=q, mask=kp)
+                assert (idx[j] == oi).all(), (queries, j)
+                assert (sim[j] == os_).all()
+    # the duplicates of the query are its nearest neighbours, in ascending index order
+    idx, _ = ops.cosine_topk(Wh, [7], 10)
+    assert idx.cpu().numpy()[0][:5].tolist() == [2343, 2344, 2400, 70_000, 149_999]
