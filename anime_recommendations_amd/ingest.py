@@ -149,8 +149,9 @@ def encode_frame(df, shuffle=True, random_state=42, min_ratings=None, device="cu
     ids = {}
     for name in ("user_id", "anime_id"):
         col = df[name].to_numpy()
-        if col.dtype.kind != "i" or (col.size and (col.max() >= 2 ** 31 or col.min() < 0)):
-            return data.encode_frame(df, shuffle=shuffle, random_state=random_state)   # ids that are not int32 >= 0
+        if col.dtype.kind not in "iu" or (col.size and (col.max() >= 2 ** 31 or col.min() < 0)):
+            raise ValueError("%s must hold non-negative integers below 2^31 (the GPU encoder's id tables are "
+                             "direct-indexed); got dtype %s" % (name, col.dtype))
         ids[name] = torch.as_tensor(col.astype(np.int32), device=device)
     ui, user_ids = encode_ids(ids["user_id"])
     ai, anime_ids = encode_ids(ids["anime_id"])
