@@ -388,6 +388,47 @@ __global__ void k_fill_self(const int32_t *queries, int nq, int32_t *self, int e
 
 static inline void head_affine(const anirec_head *h, float *hs, float *hb) { head_affine_f32(h, hs, hb); }
 
+// Few queries (<= 16; the reference's literal call has ONE): a GEMV-shaped kernel.  A workgroup stages 64 key
+// rows coalesced into LDS (pitch 132 floats: float4 rows whose 16-lane read groups fall on distinct banks) and
+// each thread runs the DEFINED k-ordered fma chain of one (key, query) pair — the same arithmetic as k_scores,
+// bit for bit — so the 64 x 64 tile kernel's 63/64 wasted lanes disappear and the pass is HBM-bound.
+constexpr int kFewQ = 16;
+constexpr int kFewPitch = kDim + 4;
+__global__ __launch_bounds__(256) void k_scores_few(ScoreArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ws[64 * kFewPitch];
+  __shared__ __attribute__((aligned(16))) float Qs[kFewQ * kDim];
+  const int tid = threadIdx.x;
+  const int j0 = blockIdx.x * 64;
+  for (int e = tid; e < 64 * kRowVec; e += 256) {
+    const int r = e >> 5, c = e & 31;
+    float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j0 + r < a.n) wv = reinterpret_cast<const float4 *>(a.W)[(size_t)(j0 + r) * kRowVec + c];
+    *reinterpret_cast<float4 *>(&Ws[r * kFewPitch + c * 4]) = wv;
+  }
+  for (int e = tid; e < a.nq * kRowVec; e += 256) {
+    const int q = e >> 5, c = e & 31;
+    const size_t src = a.qrows ? (size_t)a.qrows[q] : (size_t)q;
+    *reinterpret_cast<float4 *>(&Qs[q * kDim + c * 4]) = reinterpret_cast<const float4 *>(a.Q)[src * kRowVec + c];
+  }
+  __syncthreads();
+  const int key = tid & 63, j = j0 + key;
+  for (int q = tid >> 6; q < a.nq; q += 4) {
+    const float4 *w4 = reinterpret_cast<const float4 *>(&Ws[key * kFewPitch]);
+    const float4 *q4 = reinterpret_cast<const float4 *>(&Qs[q * kDim]);
+    float s = 0.f;
+#pragma unroll 8
+    for (int k4 = 0; k4 < kRowVec; ++k4) {
+      const float4 x = w4[k4], y = q4[k4];
+      s = __fmaf_rn(x.x, y.x, s);
+      s = __fmaf_rn(x.y, y.y, s);
+      s = __fmaf_rn(x.z, y.z, s);
+      s = __fmaf_rn(x.w, y.w, s);
+    }
+    if (a.use_head) s = rating_from_cosine(s, a.hs, a.hb);
+    if (j < a.n) a.out[(size_t)q * a.ld + j] = s;
+  }
+}
+
 // scratch of the sliced select: at most kSelMaxBlocks slice winners lists of ANIREC_MAX_TOPK entries
 constexpr int kSelMaxBlocks = 2048;
 constexpr size_t kSelTmpBytes = (size_t)kSelMaxBlocks * ANIREC_MAX_TOPK * 8;
@@ -429,6 +470,10 @@ static int launch_select(SelectArgs sa, void *tmp, hipStream_t s) {
 }
 
 static int launch_scores(const ScoreArgs &a, hipStream_t s) {
+  if (a.nq <= kFewQ) {
+    hipLaunchKernelGGL(k_scores_few, dim3((a.n + 63) / 64), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+  }
   dim3 grid((a.n + kTile - 1) / kTile, (a.nq + kTile - 1) / kTile);
   hipLaunchKernelGGL(k_scores, grid, dim3(256), 0, s, a);
   return (int)hipGetLastError();
