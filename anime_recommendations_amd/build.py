@@ -14,7 +14,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libanirec.so")
 SOURCES = ["anirec_misc.hip", "anirec_train.hip", "anirec_infer.hip", "anirec_topk_mfma.hip", "anirec_predict_mfma.hip",
-           "anirec_ingest.hip"]
+           "anirec_ingest.hip", "anirec_recs.hip"]
 
 
 def hipcc_path() -> str:

@@ -1,0 +1,425 @@
+// Favourites and user-based recommendations on the GPU: the consumer of the similar-users top-k
+// (SURVEY.md §8(f) row 4).
+//
+// Replaces, batched over every user / every query,
+//   user_recs/user_recs.py:377-404  fave_genres / fave_sources: a user's favourites are the anime they
+//       rated at or above the 80th percentile of their OWN ratings (np.percentile, linear interpolation,
+//       float64) — also similar_users/similar_users.py:203-256 get_fave_anime;
+//   user_recs/user_recs.py:708-760  similar_user_recs: for a query user, count over its similar users how
+//       often each anime is a favourite, drop the anime the query user has favourited itself, rank by count.
+// The reference does this with a pandas filter + sort per user and a DataFrame ravel + value_counts per
+// query.  Here: ratings are grouped by user (CSR built with one histogram + scan + scatter), one wave per
+// user radix-selects the two order statistics np.percentile interpolates between, a pass over the ratings
+// sets favourite bits ([n_users][n_anime/32] words), and one workgroup per query adds up its similar
+// users' bit rows into an LDS count table and selects the top n.
+// Integer / byte work, HBM-bound; bit-identical to NumPy for the thresholds and the favourite sets.
+// Ranking ties (pandas value_counts leaves their order to an unstable sort): count desc, then the best
+// (lowest) rank of a similar user holding the anime, then ascending anime index.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "anirec_dev.hpp"
+
+namespace anirec {
+
+__device__ __forceinline__ unsigned long long dkey(double d) {  // order-preserving, -0.0 == 0.0
+  const unsigned long long b = (unsigned long long)__double_as_longlong(d + 0.0);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+__device__ __forceinline__ double dkey_inv(unsigned long long o) {
+  const unsigned long long b = (o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFULL) : ~o;
+  return __longlong_as_double((long long)b);
+}
+
+__global__ __launch_bounds__(256) void k_rec_count(const int32_t *user, int64_t n, int n_users, int32_t *cnt,
+                                                   int32_t *err) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int u = user[i];
+    if (u < 0 || u >= n_users) {
+      *err = 1;
+      continue;
+    }
+    atomicAdd(&cnt[u], 1);
+  }
+}
+// exclusive scan of the per-user counts -> row pointers (one workgroup; n_users is a few 100 k)
+__global__ __launch_bounds__(1024) void k_rec_scan(const int32_t *cnt, int n_users, int64_t *ptr, int64_t *cursor) {
+  __shared__ long long part[1024];
+  const int per = (n_users + 1023) / 1024;
+  const int b0 = threadIdx.x * per, b1 = min(n_users, b0 + per);
+  long long s = 0;
+  for (int b = b0; b < b1; ++b) s += cnt[b];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long run = 0;
+    for (int t = 0; t < 1024; ++t) {
+      const long long x = part[t];
+      part[t] = run;
+      run += x;
+    }
+    ptr[n_users] = run;
+  }
+  __syncthreads();
+  long long run = part[threadIdx.x];
+  for (int b = b0; b < b1; ++b) {
+    ptr[b] = run;
+    cursor[b] = run;
+    run += cnt[b];
+  }
+}
+__global__ __launch_bounds__(256) void k_rec_scatter(const int32_t *user, const double *rating, int64_t n, int n_users,
+                                                     int64_t *cursor, double *csr_rating) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int u = user[i];
+    if (u < 0 || u >= n_users) continue;
+    const long long p = (long long)atomicAdd((unsigned long long *)&cursor[u], 1ULL);
+    csr_rating[p] = rating[i];  // order inside a user's segment is irrelevant to an order statistic
+  }
+}
+
+// np.percentile(x, pct) with the default 'linear' method, one wave per user:
+//   pos = pct/100 * (n - 1); lo = floor(pos); t = pos - lo; a = x_(lo), b = x_(lo+1)
+//   result = lerp(a, b, t) = a + (b - a) t, and b - (b - a)(1 - t) when t >= 0.5   (numpy _lerp)
+// x_(lo) comes from an 8-pass MSB radix select on the order-preserving 64-bit key of the double
+// (wave-private 256-bin histogram in LDS); x_(lo+1) is x_(lo) again if more copies of it follow, else the
+// smallest larger value.  NaN ratings never reach here (the preprocess step drops them).
+__global__ __launch_bounds__(256) void k_rec_percentile(const double *csr_rating, const int64_t *ptr, int n_users,
+                                                        double pct, double *thr) {
+  __shared__ uint32_t hist[4][256];
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  const int u = blockIdx.x * 4 + w;
+  if (u >= n_users) return;  // whole wave leaves together; no block barrier below
+  const long long s0 = ptr[u], n = ptr[u + 1] - s0;
+  if (n <= 0) {
+    if (lane == 0) thr[u] = __longlong_as_double(0x7FF8000000000000LL);  // no ratings: NaN, no favourites
+    return;
+  }
+  const double pos = (pct / 100.0) * (double)(n - 1);
+  const long long lo = (long long)floor(pos);
+  const double t = pos - (double)lo;
+  uint32_t *h = hist[w];
+  unsigned long long prefix = 0, pmask = 0;
+  long long want = lo;  // 0-based rank (ascending) still to locate inside the prefix
+  for (int pass = 0; pass < 8; ++pass) {
+    const int shift = 56 - 8 * pass;
+    for (int b = lane; b < 256; b += 64) h[b] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (long long i = lane; i < n; i += 64) {
+      const unsigned long long k = dkey(csr_rating[s0 + i]);
+      if ((k & pmask) == prefix) atomicAdd(&h[(k >> shift) & 255ull], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ascending digit walk by a wave scan: lane l covers digits 4l .. 4l+3
+    uint32_t h4[4], run = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      h4[j] = h[4 * lane + j];
+      run += h4[j];
+    }
+    uint32_t inc = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += y;
+    }
+    const unsigned long long reach = __ballot((long long)inc > want);
+    const int src = __ffsll((long long)reach) - 1;  // reach != 0: want < n
+    long long cum = (long long)(inc - run);
+    int d = 4 * lane;
+    if (lane == src) {
+      int j = 0;
+      for (; j < 3; ++j) {
+        if (cum + (long long)h4[j] > want) break;
+        cum += h4[j];
+      }
+      d = 4 * lane + j;
+    }
+    d = __shfl(d, src, 64);
+    cum = __shfl(cum, src, 64);
+    prefix |= (unsigned long long)d << shift;
+    pmask |= 255ull << shift;
+    want -= cum;
+    __builtin_amdgcn_wave_barrier();
+  }
+  const unsigned long long ka = prefix;  // key of x_(lo)
+  // copies of x_(lo) up to and including rank lo: want + 1 of them are needed to reach rank lo; if the
+  // segment holds more, x_(lo+1) is the same value
+  long long n_eq = 0;
+  unsigned long long kmin_gt = ~0ull;
+  for (long long i = lane; i < n; i += 64) {
+    const unsigned long long k = dkey(csr_rating[s0 + i]);
+    if (k == ka) ++n_eq;
+    if (k > ka && k < kmin_gt) kmin_gt = k;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    n_eq += __shfl_xor(n_eq, o, 64);
+    const unsigned long long y = __shfl_xor(kmin_gt, o, 64);
+    kmin_gt = y < kmin_gt ? y : kmin_gt;
+  }
+  if (lane == 0) {
+    const double a = dkey_inv(ka);
+    double b = a;
+    if (lo + 1 < n && n_eq <= want + 1) b = dkey_inv(kmin_gt);
+    // numpy.lib.function_base._lerp (contraction off: plain IEEE double operations)
+    double r;
+    {
+#pragma clang fp contract(off)
+      const double diff = b - a;
+      r = a + diff * t;
+      if (t >= 0.5) r = b - diff * (1.0 - t);
+      if (t == 0.0) r = a;  // (numpy: where(t == 0, a, ...) is implied by a + 0; kept explicit for -0.0)
+    }
+    thr[u] = r;
+  }
+}
+
+// favourite bits: rating >= the user's own threshold (user_recs.py:394 `watched.rating >= percentile`)
+__global__ __launch_bounds__(256) void k_rec_favbits(const int32_t *user, const int32_t *anime, const double *rating,
+                                                     int64_t n, int n_users, int n_anime, const double *thr,
+                                                     uint32_t *fav, int wwords, int32_t *err) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int u = user[i], a = anime[i];
+    if (u < 0 || u >= n_users) continue;
+    if (a < 0 || a >= n_anime) {
+      *err = 1;
+      continue;
+    }
+    if (rating[i] >= thr[u]) atomicOr(&fav[(size_t)u * wwords + (a >> 5)], 1u << (a & 31));
+  }
+}
+
+// One workgroup per query: counts[a] = number of similar users holding a as a favourite (a not a favourite
+// of the query user), best[a] = lowest rank of such a similar user; then the top n by
+// (count desc, best rank asc, anime index asc) with a radix-free threshold search (counts <= k_sim).
+struct RecsArgs {
+  const uint32_t *fav;
+  int n_users, n_anime, wwords;
+  const int32_t *query;  // [nq]
+  const int32_t *sim;    // [nq][k_sim], -1 = empty slot, best first
+  int nq, k_sim, n_recs;
+  int32_t *out_anime;    // [nq][n_recs], -1 padded
+  int32_t *out_count;    // [nq][n_recs], 0 padded
+};
+constexpr int kRecsMaxSim = 64;
+
+__global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
+  extern __shared__ uint32_t sm[];  // key[n_anime_padded]: (count << 8) | (255 - best_rank), 0 = not recommended
+  __shared__ int hist[kRecsMaxSim + 1], hist2[kRecsMaxSim + 1];
+  __shared__ int sh_cut, sh_room, sh_cut_b, sh_room2;
+  __shared__ int wsum[4];
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const int qu = a.query[q];
+  const int n_pad = a.wwords * 32;
+  for (int w = tid; w < a.wwords; w += 256) {
+    uint32_t cnt[32];
+    uint32_t best[32];
+#pragma unroll
+    for (int b = 0; b < 32; ++b) {
+      cnt[b] = 0;
+      best[b] = 255;
+    }
+    for (int j = 0; j < a.k_sim; ++j) {
+      const int su = a.sim[(size_t)q * a.k_sim + j];
+      if (su < 0 || su >= a.n_users) continue;
+      uint32_t bits = a.fav[(size_t)su * a.wwords + w];
+      while (bits) {
+        const int b = __ffs((int)bits) - 1;
+        bits &= bits - 1;
+        cnt[b] += 1;
+        if (best[b] == 255) best[b] = j;  // similar users come best first: the first holder is the best rank
+      }
+    }
+    const uint32_t own = (qu >= 0 && qu < a.n_users) ? a.fav[(size_t)qu * a.wwords + w] : 0u;
+#pragma unroll
+    for (int b = 0; b < 32; ++b) {
+      const int an = w * 32 + b;
+      const bool ok = cnt[b] != 0 && !((own >> b) & 1u) && an < a.n_anime;
+      sm[an] = ok ? ((cnt[b] << 8) | (255u - best[b])) : 0u;
+    }
+  }
+  for (int c = tid; c <= kRecsMaxSim; c += 256) {
+    hist[c] = 0;
+    hist2[c] = 0;
+  }
+  __syncthreads();
+  // level 1: histogram of counts -> the count value `cut` at which the top n_recs end
+  for (int an = tid; an < n_pad; an += 256) {
+    const uint32_t k = sm[an];
+    if (k) atomicAdd(&hist[k >> 8], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int cum = 0, c = a.k_sim;
+    for (; c >= 1; --c) {
+      if (cum + hist[c] >= a.n_recs) break;
+      cum += hist[c];
+    }
+    sh_cut = c;                // counts > cut are all taken (cut == 0: fewer than n_recs candidates, all taken)
+    sh_room = a.n_recs - cum;  // entries still to take among those with count == cut
+  }
+  __syncthreads();
+  const int cut = sh_cut;
+  // level 2: among count == cut, histogram of the best similar-user rank -> rank `cut_b`
+  if (cut > 0) {
+    for (int an = tid; an < n_pad; an += 256) {
+      const uint32_t k = sm[an];
+      if (k && (int)(k >> 8) == cut) atomicAdd(&hist2[255 - (int)(k & 255u)], 1);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int cum = 0, r = 0;
+    if (cut > 0) {
+      for (; r < a.k_sim; ++r) {
+        if (cum + hist2[r] >= sh_room) break;
+        cum += hist2[r];
+      }
+    }
+    sh_cut_b = r;               // best rank < cut_b: taken; == cut_b: the first `room2` in anime-index order
+    sh_room2 = sh_room - cum;
+  }
+  __syncthreads();
+  const int cut_b = sh_cut_b, room2 = sh_room2;
+  // level 3 + compaction (stable, anime index ascending): winners move to the front of sm as packed words
+  // count (7 bits) | 255 - best (8 bits) | anime (17 bits); exactly min(n_recs, #candidates) of them
+  int n_out = 0, tie_seen = 0;
+  for (int base = 0; base < n_pad; base += 256) {
+    const int an = base + tid;
+    const uint32_t k = an < n_pad ? sm[an] : 0u;
+    const int cnt = (int)(k >> 8), best = 255 - (int)(k & 255u);
+    const bool sure = k != 0u && (cut == 0 || cnt > cut || (cnt == cut && best < cut_b));
+    const bool tie = k != 0u && cut > 0 && cnt == cut && best == cut_b;
+    const int lane = tid & 63, w = tid >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long mt = __ballot(tie);
+    if (lane == 0) wsum[w] = __popcll(mt);
+    __syncthreads();
+    int tie_off = tie_seen;
+    for (int x = 0; x < w; ++x) tie_off += wsum[x];
+    const int tie_tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const bool take = sure || (tie && tie_off + __popcll(mt & below) < room2);
+    __syncthreads();
+    const unsigned long long m = __ballot(take);
+    if (lane == 0) wsum[w] = __popcll(m);
+    __syncthreads();
+    int off = n_out;
+    for (int x = 0; x < w; ++x) off += wsum[x];
+    const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const int pos = off + __popcll(m & below);  // pos <= an: winners only move towards the front
+    __syncthreads();                            // every read of this chunk happened above
+    if (take) sm[pos] = ((uint32_t)cnt << 25) | ((k & 255u) << 17) | (uint32_t)an;
+    n_out += tot;
+    tie_seen += tie_tot;
+    __syncthreads();
+  }
+  // exact order of the n_out (<= n_recs) winners: (count, 255 - best) descending, anime index ascending
+  for (int i = tid; i < a.n_recs; i += 256) {
+    a.out_anime[(size_t)q * a.n_recs + i] = -1;
+    a.out_count[(size_t)q * a.n_recs + i] = 0;
+  }
+  __syncthreads();
+  for (int i = tid; i < n_out; i += 256) {
+    const uint32_t me = sm[i];
+    const uint32_t mk = me >> 17, ma = me & 0x1FFFFu;
+    int rank = 0;
+    for (int j = 0; j < n_out; ++j) {
+      const uint32_t o = sm[j];
+      const uint32_t ok = o >> 17, oa = o & 0x1FFFFu;
+      rank += (ok > mk || (ok == mk && oa < ma)) ? 1 : 0;
+    }
+    if (rank < a.n_recs) {
+      a.out_anime[(size_t)q * a.n_recs + rank] = (int32_t)ma;
+      a.out_count[(size_t)q * a.n_recs + rank] = (int32_t)(me >> 25);
+    }
+  }
+}
+
+static inline size_t al256r(size_t x) { return (x + 255) / 256 * 256; }
+static inline int grid_rec(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 16384) b = 16384;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace anirec
+
+using namespace anirec;
+
+extern "C" {
+
+// cnt | ptr | cursor | csr_rating
+size_t anirec_fav_workspace_bytes(int64_t n_ratings, int32_t n_users) {
+  if (n_ratings < 1 || n_users < 1) return 0;
+  return al256r((size_t)n_users * 4) + 2 * al256r(((size_t)n_users + 1) * 8) + al256r((size_t)n_ratings * 8) + 256;
+}
+
+int anirec_user_favourites(const int32_t *user_idx, const int32_t *anime_idx, const double *rating, int64_t n,
+                           int32_t n_users, int32_t n_anime, double percentile, uint32_t *fav_bits,
+                           double *threshold, int32_t *err_flag, void *workspace, size_t workspace_bytes,
+                           void *stream) {
+  if (!user_idx || !anime_idx || !rating || !fav_bits || !threshold || !err_flag || !workspace) return ANIREC_EINVAL;
+  if (n < 1 || n_users < 1 || n_anime < 1 || !(percentile >= 0.0 && percentile <= 100.0)) return ANIREC_EINVAL;
+  if (workspace_bytes < anirec_fav_workspace_bytes(n, n_users)) return ANIREC_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  char *p = (char *)workspace;
+  int32_t *cnt = (int32_t *)p;
+  p += al256r((size_t)n_users * 4);
+  int64_t *ptr = (int64_t *)p;
+  p += al256r(((size_t)n_users + 1) * 8);
+  int64_t *cursor = (int64_t *)p;
+  p += al256r(((size_t)n_users + 1) * 8);
+  double *csr = (double *)p;
+  const int wwords = (n_anime + 31) / 32;
+  ANIREC_HIP_CHECK(hipMemsetAsync(err_flag, 0, 4, s));
+  ANIREC_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)n_users * 4, s));
+  ANIREC_HIP_CHECK(hipMemsetAsync(fav_bits, 0, (size_t)n_users * wwords * 4, s));
+  const int g = grid_rec(n);
+  hipLaunchKernelGGL(k_rec_count, dim3(g), dim3(256), 0, s, user_idx, n, n_users, cnt, err_flag);
+  hipLaunchKernelGGL(k_rec_scan, dim3(1), dim3(1024), 0, s, cnt, n_users, ptr, cursor);
+  hipLaunchKernelGGL(k_rec_scatter, dim3(g), dim3(256), 0, s, user_idx, rating, n, n_users, cursor, csr);
+  hipLaunchKernelGGL(k_rec_percentile, dim3((n_users + 3) / 4), dim3(256), 0, s, csr, ptr, n_users, percentile,
+                     threshold);
+  hipLaunchKernelGGL(k_rec_favbits, dim3(g), dim3(256), 0, s, user_idx, anime_idx, rating, n, n_users, n_anime,
+                     threshold, fav_bits, wwords, err_flag);
+  return (int)hipGetLastError();
+}
+
+int anirec_user_recs(const uint32_t *fav_bits, int32_t n_users, int32_t n_anime, const int32_t *query_users,
+                     const int32_t *sim_users, int32_t nq, int32_t k_sim, int32_t n_recs, int32_t *out_anime,
+                     int32_t *out_count, void *stream) {
+  if (!fav_bits || !query_users || !sim_users || !out_anime || !out_count) return ANIREC_EINVAL;
+  if (n_users < 1 || n_anime < 1 || n_anime >= (1 << 17) || nq < 0 || k_sim < 1 || k_sim > kRecsMaxSim || n_recs < 1)
+    return ANIREC_EINVAL;
+  if (nq == 0) return ANIREC_OK;
+  const int wwords = (n_anime + 31) / 32;
+  RecsArgs a;
+  a.fav = fav_bits;
+  a.n_users = n_users;
+  a.n_anime = n_anime;
+  a.wwords = wwords;
+  a.query = query_users;
+  a.sim = sim_users;
+  a.nq = nq;
+  a.k_sim = k_sim;
+  a.n_recs = n_recs;
+  a.out_anime = out_anime;
+  a.out_count = out_count;
+  const size_t shm = (size_t)wwords * 32 * 4;  // one word per anime: 72 KB at 18 k anime
+  if (shm > 150 * 1024) return ANIREC_EINVAL;
+  static bool attr_set = false;
+  if (!attr_set) {
+    ANIREC_HIP_CHECK(hipFuncSetAttribute((const void *)k_user_recs, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_user_recs, dim3(nq), dim3(256), shm, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

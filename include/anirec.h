@@ -307,6 +307,30 @@ int anirec_ingest_encode(const int32_t *id, int64_t n, int32_t id_bound, int32_t
                          int32_t *out_uniques, int64_t *n_unique, int32_t *err_flag, void *workspace,
                          size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------- *
+ *  FAVOURITES + USER-BASED RECS — the consumer of the similar-users top-k.
+ *  user_recs/user_recs.py:377-404 (fave_genres: a user's favourites are the anime rated at or above
+ *  the 80th percentile of their own ratings, np.percentile 'linear', float64; also
+ *  similar_users.py:203-256 get_fave_anime) and :708-760 (similar_user_recs: per query user, count how
+ *  many of its similar users hold each anime as a favourite, drop the query's own favourites, rank).
+ * ------------------------------------------------------------------------- */
+
+/* fav_bits[n_users][ceil(n_anime/32)]: bit a of row u set iff rating(u, a) >= threshold[u];
+ * threshold[u] = np.percentile(ratings of u, percentile) bit for bit (NaN for users without ratings).
+ * Ratings must not contain NaN.  *err_flag (device) becomes 1 on an out-of-range index. */
+size_t anirec_fav_workspace_bytes(int64_t n_ratings, int32_t n_users);
+int anirec_user_favourites(const int32_t *user_idx, const int32_t *anime_idx, const double *rating, int64_t n,
+                           int32_t n_users, int32_t n_anime, double percentile, uint32_t *fav_bits,
+                           double *threshold, int32_t *err_flag, void *workspace, size_t workspace_bytes,
+                           void *stream);
+
+/* sim_users[nq][k_sim]: similar users of query_users[q], best first, -1 = empty (k_sim <= 64).
+ * out_anime/out_count[nq][n_recs]: anime by (count desc, best similar-user rank asc, anime index asc),
+ * -1 / 0 padded; anime that are favourites of the query user are skipped.  n_anime < 131072. */
+int anirec_user_recs(const uint32_t *fav_bits, int32_t n_users, int32_t n_anime, const int32_t *query_users,
+                     const int32_t *sim_users, int32_t nq, int32_t k_sim, int32_t n_recs, int32_t *out_anime,
+                     int32_t *out_count, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
