@@ -207,9 +207,13 @@ struct RecsArgs {
   int32_t *out_count;    // [nq][n_recs], 0 padded
 };
 constexpr int kRecsMaxSim = 64;
+constexpr int kRecsMaxOut = 256;
 
 __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
-  extern __shared__ uint32_t sm[];  // key[n_anime_padded]: (count << 8) | (255 - best_rank), 0 = not recommended
+  // key[anime] = (count << 6) | (63 - best_rank), 0 = not recommended: 2 B per anime (36 KB at 18 k anime,
+  // four workgroups per CU)
+  extern __shared__ uint16_t sm[];
+  __shared__ uint32_t win[kRecsMaxOut];  // winners: count (7 bits) | 63 - best (8 bits) | anime (17 bits)
   __shared__ int hist[kRecsMaxSim + 1], hist2[kRecsMaxSim + 1];
   __shared__ int sh_cut, sh_room, sh_cut_b, sh_room2;
   __shared__ int wsum[4];
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
 #pragma unroll
     for (int b = 0; b < 32; ++b) {
       cnt[b] = 0;
-      best[b] = 255;
+      best[b] = 63;
     }
     for (int j = 0; j < a.k_sim; ++j) {
       const int su = a.sim[(size_t)q * a.k_sim + j];
@@ -231,8 +235,8 @@ __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
       while (bits) {
         const int b = __ffs((int)bits) - 1;
         bits &= bits - 1;
+        if (cnt[b] == 0) best[b] = j;  // similar users come best first: the first holder is the best rank
         cnt[b] += 1;
-        if (best[b] == 255) best[b] = j;  // similar users come best first: the first holder is the best rank
       }
     }
     const uint32_t own = (qu >= 0 && qu < a.n_users) ? a.fav[(size_t)qu * a.wwords + w] : 0u;
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
     for (int b = 0; b < 32; ++b) {
       const int an = w * 32 + b;
       const bool ok = cnt[b] != 0 && !((own >> b) & 1u) && an < a.n_anime;
-      sm[an] = ok ? ((cnt[b] << 8) | (255u - best[b])) : 0u;
+      sm[an] = ok ? (uint16_t)((cnt[b] << 6) | (63u - best[b])) : (uint16_t)0;
     }
   }
   for (int c = tid; c <= kRecsMaxSim; c += 256) {
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
   // level 1: histogram of counts -> the count value `cut` at which the top n_recs end
   for (int an = tid; an < n_pad; an += 256) {
     const uint32_t k = sm[an];
-    if (k) atomicAdd(&hist[k >> 8], 1);
+    if (k) atomicAdd(&hist[k >> 6], 1);
   }
   __syncthreads();
   if (tid == 0) {
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
   if (cut > 0) {
     for (int an = tid; an < n_pad; an += 256) {
       const uint32_t k = sm[an];
-      if (k && (int)(k >> 8) == cut) atomicAdd(&hist2[255 - (int)(k & 255u)], 1);
+      if (k && (int)(k >> 6) == cut) atomicAdd(&hist2[63 - (int)(k & 63u)], 1);
     }
   }
   __syncthreads();
@@ -286,15 +290,15 @@ __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
   }
   __syncthreads();
   const int cut_b = sh_cut_b, room2 = sh_room2;
-  // level 3 + compaction (stable, anime index ascending): winners move to the front of sm as packed words
-  // count (7 bits) | 255 - best (8 bits) | anime (17 bits); exactly min(n_recs, #candidates) of them
+  // level 3 + gather (anime index ascending): exactly min(n_recs, #candidates) winners
   int n_out = 0, tie_seen = 0;
   for (int base = 0; base < n_pad; base += 256) {
     const int an = base + tid;
     const uint32_t k = an < n_pad ? sm[an] : 0u;
-    const int cnt = (int)(k >> 8), best = 255 - (int)(k & 255u);
+    const int cnt = (int)(k >> 6), best = 63 - (int)(k & 63u);
     const bool sure = k != 0u && (cut == 0 || cnt > cut || (cnt == cut && best < cut_b));
     const bool tie = k != 0u && cut > 0 && cnt == cut && best == cut_b;
+    if (!__syncthreads_or(sure || tie)) continue;  // most 256-anime chunks hold no winner: one barrier, not four
     const int lane = tid & 63, w = tid >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
     const unsigned long long mt = __ballot(tie);
@@ -311,25 +315,25 @@ __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
     int off = n_out;
     for (int x = 0; x < w; ++x) off += wsum[x];
     const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    const int pos = off + __popcll(m & below);  // pos <= an: winners only move towards the front
-    __syncthreads();                            // every read of this chunk happened above
-    if (take) sm[pos] = ((uint32_t)cnt << 25) | ((k & 255u) << 17) | (uint32_t)an;
+    const int pos = off + __popcll(m & below);
+    if (take && pos < kRecsMaxOut) win[pos] = ((uint32_t)cnt << 25) | ((k & 63u) << 17) | (uint32_t)an;
     n_out += tot;
     tie_seen += tie_tot;
     __syncthreads();
   }
-  // exact order of the n_out (<= n_recs) winners: (count, 255 - best) descending, anime index ascending
+  if (n_out > kRecsMaxOut) n_out = kRecsMaxOut;
+  // exact order of the n_out (<= n_recs) winners: (count, 63 - best) descending, anime index ascending
   for (int i = tid; i < a.n_recs; i += 256) {
     a.out_anime[(size_t)q * a.n_recs + i] = -1;
     a.out_count[(size_t)q * a.n_recs + i] = 0;
   }
   __syncthreads();
   for (int i = tid; i < n_out; i += 256) {
-    const uint32_t me = sm[i];
+    const uint32_t me = win[i];
     const uint32_t mk = me >> 17, ma = me & 0x1FFFFu;
     int rank = 0;
     for (int j = 0; j < n_out; ++j) {
-      const uint32_t o = sm[j];
+      const uint32_t o = win[j];
       const uint32_t ok = o >> 17, oa = o & 0x1FFFFu;
       rank += (ok > mk || (ok == mk && oa < ma)) ? 1 : 0;
     }
@@ -395,7 +399,8 @@ int anirec_user_recs(const uint32_t *fav_bits, int32_t n_users, int32_t n_anime,
                      const int32_t *sim_users, int32_t nq, int32_t k_sim, int32_t n_recs, int32_t *out_anime,
                      int32_t *out_count, void *stream) {
   if (!fav_bits || !query_users || !sim_users || !out_anime || !out_count) return ANIREC_EINVAL;
-  if (n_users < 1 || n_anime < 1 || n_anime >= (1 << 17) || nq < 0 || k_sim < 1 || k_sim > kRecsMaxSim || n_recs < 1)
+  if (n_users < 1 || n_anime < 1 || n_anime >= (1 << 17) || nq < 0 || k_sim < 1 || k_sim > kRecsMaxSim - 1 ||
+      n_recs < 1 || n_recs > kRecsMaxOut)
     return ANIREC_EINVAL;
   if (nq == 0) return ANIREC_OK;
   const int wwords = (n_anime + 31) / 32;
@@ -411,7 +416,7 @@ int anirec_user_recs(const uint32_t *fav_bits, int32_t n_users, int32_t n_anime,
   a.n_recs = n_recs;
   a.out_anime = out_anime;
   a.out_count = out_count;
-  const size_t shm = (size_t)wwords * 32 * 4;  // one word per anime: 72 KB at 18 k anime
+  const size_t shm = (size_t)wwords * 32 * 2;  // 2 B per anime: 36 KB at 18 k anime
   if (shm > 150 * 1024) return ANIREC_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {

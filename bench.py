@@ -375,6 +375,69 @@ def run_predict_topk(cpu_baseline=True):
     return rec
 
 
+def run_user_recs(cpu_baseline=True):
+    """favourites of every user (80th percentile of their own ratings) from 109 M
+    ratings, then for 65 536 query users the 10 anime their 10 most similar users favourited most."""
+    import torch
+    from anime_recommendations_amd import ops, recs
+    n_users, n_anime, n = 350_000, 18_000, 109_000_000
+    dev = torch.device("cuda")
+    ui, ai, t = synth_ratings(n_users, n_anime, n, dev)
+    r = t.double()
+    recs.user_favourites(ui, ai, r, n_users, n_anime)
+    torch.cuda.synchronize()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fav, thr = recs.user_favourites(ui, ai, r, n_users, n_anime)
+    torch.cuda.synchronize()
+    dt_f = (time.perf_counter() - t0) / reps
+    nq, k_sim, n_recs = 65_536, 10, 10
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    U = torch.randn(n_users, 128, generator=g, device="cuda") * 0.05
+    q = torch.arange(nq, dtype=torch.int32, device="cuda")
+    sim, _, _ = ops.cosine_topk_mfma(ops.rownorm(U), q, k_sim)
+    recs.user_recs(fav, n_anime, q, sim, n_recs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out_a, out_c = recs.user_recs(fav, n_anime, q, sim, n_recs)
+    torch.cuda.synchronize()
+    dt_r = (time.perf_counter() - t0) / reps
+    ww = (n_anime + 31) // 32
+    fav_bytes = 16 * n + 16 * n + (n_users * ww * 4)      # count+scatter pass, percentile + bit pass, bit rows written
+    rec_bytes = nq * (k_sim + 1) * ww * 4                 # the similar users' and the query's bit rows
+    rec = {"value": nq / dt_r, "unit": "queries/s", "ms": dt_r * 1e3,
+           "favourites": {"ms": dt_f * 1e3, "ratings_per_s": n / dt_f,
+                          "roofline": {"kernel": "k_rec_count/scatter/percentile/favbits (5 launches)", "bound": "hbm",
+                                       "achieved": fav_bytes / dt_f / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": fav_bytes / dt_f / 1e9 / HBM_PEAK_GBS, "traffic": None}},
+           "roofline": {"kernel": "k_user_recs (one workgroup per query: 11 bit rows of 2.25 KB -> LDS counts -> top-10)",
+                        "bound": "hbm", "achieved": rec_bytes / dt_r / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": rec_bytes / dt_r / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+    if cpu_baseline:
+        from oracle import recs_oracle
+        nu_s = 2_000                                       # users 0..1999 of the same table
+        m = (ui < nu_s)
+        us, as_, rs = ui[m].cpu().numpy(), ai[m].cpu().numpy(), r[m].cpu().numpy()
+        t0 = time.perf_counter()
+        _, fav_o = recs_oracle.favourites(us, as_, rs, nu_s)
+        dtf = time.perf_counter() - t0
+        rng = np.random.default_rng(0)
+        t0 = time.perf_counter()
+        for qq in range(200):
+            recs_oracle.value_counts_of_similar_favourites(fav_o, qq, rng.integers(0, nu_s, k_sim).tolist())
+        dtr = time.perf_counter() - t0
+        rec["cpu_baseline"] = {"value": 200 / dtr, "unit": "queries/s", "cores": 1, "kind": "port",
+                               "favourites_users_per_s": nu_s / dtf,
+                               "sample": "%d users: np.percentile + filter per user; 200 queries: pandas ravel + "
+                                         "value_counts (user_recs.py:377-404, :732-745)" % nu_s}
+    del ui, ai, t, r, U, fav
+    torch.cuda.empty_cache()
+    return rec
+
+
 def run_gather_roofline():
     """The embedding-forward kernel body (two 512-B row gathers + three dot-128 reductions per rating,
     k_predict_pairs == k_fwd without the batch bookkeeping) on 4 M random pairs: the HBM gather rate
@@ -492,6 +555,7 @@ def main():
         line["also"]["predict_topk_100k_users_x_18k"] = run_predict_topk(cpu_baseline=not args.no_cpu_baseline)
         line["also"]["embed_fwd_gather_4M_pairs"] = run_gather_roofline()
         line["also"]["ingest_109m_rows"] = run_ingest(cpu_baseline=not args.no_cpu_baseline)
+        line["also"]["user_recs_65536_queries"] = run_user_recs(cpu_baseline=not args.no_cpu_baseline)
     print(json.dumps(line))
 
 

@@ -324,7 +324,7 @@ int anirec_user_favourites(const int32_t *user_idx, const int32_t *anime_idx, co
                            double *threshold, int32_t *err_flag, void *workspace, size_t workspace_bytes,
                            void *stream);
 
-/* sim_users[nq][k_sim]: similar users of query_users[q], best first, -1 = empty (k_sim <= 64).
+/* sim_users[nq][k_sim]: similar users of query_users[q], best first, -1 = empty (k_sim <= 63, n_recs <= 256).
  * out_anime/out_count[nq][n_recs]: anime by (count desc, best similar-user rank asc, anime index asc),
  * -1 / 0 padded; anime that are favourites of the query user are skipped.  n_anime < 131072. */
 int anirec_user_recs(const uint32_t *fav_bits, int32_t n_users, int32_t n_anime, const int32_t *query_users,
