@@ -159,3 +159,21 @@ def test_ingest_oracle_hand_example():
     assert out["anime_id"].tolist() == [5, 6, 5, 7, 8]
     idx, uniq = ing.encode(pd.Series([7, 3, 7, 9, 3]))
     assert idx.tolist() == [0, 1, 0, 2, 1] and uniq.tolist() == [7, 3, 9]
+
+
+def test_recs_oracle_hand_example():
+    """Pins the NumPy/pandas restatement of fave_genres / similar_user_recs on a case done by hand."""
+    from oracle import recs_oracle as rec
+    # user 0 rates five anime 0.2 .. 1.0: 80th percentile of [.2,.4,.6,.8,1.] = .2 + .8*4*(.2) -> position 3.2
+    u = np.array([0, 0, 0, 0, 0, 1, 1, 2, 2, 2])
+    a = np.array([0, 1, 2, 3, 4, 3, 4, 4, 5, 6])
+    r = np.array([.2, .4, .6, .8, 1., .5, .7, .9, .9, .1])
+    thr, fav = rec.favourites(u, a, r, 4)
+    assert thr[0] == np.percentile([.2, .4, .6, .8, 1.], 80) and abs(thr[0] - 0.84) < 1e-12
+    assert fav[0] == {4} and fav[1] == {4} and fav[2] == {4, 5} and fav[3] == set() and np.isnan(thr[3])
+    # query user 3 (no favourites of its own), similar users 2, 0, 1 (best first): anime 4 three times, 5 once
+    order, counts = rec.user_recs(fav, 3, [2, 0, 1], 5)
+    assert order == [4, 5] and counts == [3, 1]
+    assert rec.value_counts_of_similar_favourites(fav, 3, [2, 0, 1]) == {4: 3, 5: 1}
+    # query user 0 holds anime 4 itself: only 5 is left
+    assert rec.user_recs(fav, 0, [2, 1], 5) == ([5], [1])
