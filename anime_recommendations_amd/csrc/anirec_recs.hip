@@ -32,49 +32,75 @@ __device__ __forceinline__ double dkey_inv(unsigned long long o) {
   return __longlong_as_double((long long)b);
 }
 
+// Per-user counts.  The rating table usually arrives grouped by user (the raw / preprocessed order): a wave
+// adds one atomic per RUN of equal users among its 64 consecutive rows, and `unsorted` records whether any
+// row breaks the non-decreasing order — if none does, the table already IS the CSR payload.
 __global__ __launch_bounds__(256) void k_rec_count(const int32_t *user, int64_t n, int n_users, int32_t *cnt,
-                                                   int32_t *err) {
+                                                   int32_t *err, int32_t *unsorted) {
+  const int lane = lane_id();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n_round = (n + 63) / 64 * 64;  // whole waves stay converged for the shuffles
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+    int u = i < n ? user[i] : -1;
+    if (i < n && (u < 0 || u >= n_users)) {
+      *err = 1;
+      u = -1;
+    }
+    int left = __shfl_up(u, 1, 64);
+    if (lane == 0) left = (i > 0 && i < n) ? user[i - 1] : u;
+    if (i < n && u < left) *unsorted = 1;
+    const bool head = lane == 0 || u != __shfl_up(u, 1, 64);
+    const unsigned long long heads = __ballot(head);
+    if (head && u >= 0) {
+      const unsigned long long later = lane == 63 ? 0ULL : heads >> (lane + 1);
+      const int len = later ? __ffsll((long long)later) : 64 - lane;
+      atomicAdd(&cnt[u], len);
+    }
+  }
+}
+// exclusive scan of the per-user counts -> row pointers: one workgroup walks coalesced tiles of 1024
+__global__ __launch_bounds__(1024) void k_rec_scan(const int32_t *cnt, int n_users, int64_t *ptr, int64_t *cursor) {
+  __shared__ long long wtot[16];
+  __shared__ long long carry_s;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n_users; base += 1024) {
+    const int i = base + threadIdx.x;
+    const long long v = i < n_users ? cnt[i] : 0;
+    long long inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const long long y = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += y;
+    }
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    long long off = carry_s;
+    for (int x = 0; x < w; ++x) off += wtot[x];
+    if (i < n_users) {
+      ptr[i] = off + inc - v;
+      cursor[i] = off + inc - v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = off + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ptr[n_users] = carry_s;
+}
+// CSR payload: a straight copy when the table is grouped by user, an atomic-cursor scatter otherwise
+__global__ __launch_bounds__(256) void k_rec_scatter(const int32_t *user, const double *rating, int64_t n, int n_users,
+                                                     int64_t *cursor, const int32_t *unsorted, double *csr_rating) {
+  const bool grouped = *unsorted == 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int u = user[i];
-    if (u < 0 || u >= n_users) {
-      *err = 1;
+    if (grouped) {
+      // out-of-range users were excluded from the counts: they break neither the order test nor ptr[] only if
+      // absent, and err_flag reports them; the copy keeps positions aligned with ptr[] for valid tables
+      csr_rating[i] = rating[i];
       continue;
     }
-    atomicAdd(&cnt[u], 1);
-  }
-}
-// exclusive scan of the per-user counts -> row pointers (one workgroup; n_users is a few 100 k)
-__global__ __launch_bounds__(1024) void k_rec_scan(const int32_t *cnt, int n_users, int64_t *ptr, int64_t *cursor) {
-  __shared__ long long part[1024];
-  const int per = (n_users + 1023) / 1024;
-  const int b0 = threadIdx.x * per, b1 = min(n_users, b0 + per);
-  long long s = 0;
-  for (int b = b0; b < b1; ++b) s += cnt[b];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    long long run = 0;
-    for (int t = 0; t < 1024; ++t) {
-      const long long x = part[t];
-      part[t] = run;
-      run += x;
-    }
-    ptr[n_users] = run;
-  }
-  __syncthreads();
-  long long run = part[threadIdx.x];
-  for (int b = b0; b < b1; ++b) {
-    ptr[b] = run;
-    cursor[b] = run;
-    run += cnt[b];
-  }
-}
-__global__ __launch_bounds__(256) void k_rec_scatter(const int32_t *user, const double *rating, int64_t n, int n_users,
-                                                     int64_t *cursor, double *csr_rating) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int u = user[i];
     if (u < 0 || u >= n_users) continue;
     const long long p = (long long)atomicAdd((unsigned long long *)&cursor[u], 1ULL);
     csr_rating[p] = rating[i];  // order inside a user's segment is irrelevant to an order statistic
@@ -381,13 +407,15 @@ int anirec_user_favourites(const int32_t *user_idx, const int32_t *anime_idx, co
   p += al256r(((size_t)n_users + 1) * 8);
   double *csr = (double *)p;
   const int wwords = (n_anime + 31) / 32;
+  int32_t *unsorted = (int32_t *)((char *)csr + al256r((size_t)n * 8));  // the spare 256 B at the end
   ANIREC_HIP_CHECK(hipMemsetAsync(err_flag, 0, 4, s));
+  ANIREC_HIP_CHECK(hipMemsetAsync(unsorted, 0, 4, s));
   ANIREC_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)n_users * 4, s));
   ANIREC_HIP_CHECK(hipMemsetAsync(fav_bits, 0, (size_t)n_users * wwords * 4, s));
   const int g = grid_rec(n);
-  hipLaunchKernelGGL(k_rec_count, dim3(g), dim3(256), 0, s, user_idx, n, n_users, cnt, err_flag);
+  hipLaunchKernelGGL(k_rec_count, dim3(g), dim3(256), 0, s, user_idx, n, n_users, cnt, err_flag, unsorted);
   hipLaunchKernelGGL(k_rec_scan, dim3(1), dim3(1024), 0, s, cnt, n_users, ptr, cursor);
-  hipLaunchKernelGGL(k_rec_scatter, dim3(g), dim3(256), 0, s, user_idx, rating, n, n_users, cursor, csr);
+  hipLaunchKernelGGL(k_rec_scatter, dim3(g), dim3(256), 0, s, user_idx, rating, n, n_users, cursor, unsorted, csr);
   hipLaunchKernelGGL(k_rec_percentile, dim3((n_users + 3) / 4), dim3(256), 0, s, csr, ptr, n_users, percentile,
                      threshold);
   hipLaunchKernelGGL(k_rec_favbits, dim3(g), dim3(256), 0, s, user_idx, anime_idx, rating, n, n_users, n_anime,

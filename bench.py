@@ -383,10 +383,14 @@ def run_user_recs(cpu_baseline=True):
     n_users, n_anime, n = 350_000, 18_000, 109_000_000
     dev = torch.device("cuda")
     ui, ai, t = synth_ratings(n_users, n_anime, n, dev)
+    order = torch.sort(ui, stable=True)[1]            # the rating table in its raw order: grouped by user
+    ui, ai, t = ui[order], ai[order], t[order]
+    del order
     r = t.double()
-    recs.user_favourites(ui, ai, r, n_users, n_anime)
+    for _ in range(3):          # the two 0.8 GB result / workspace blocks settle in torch's caching allocator
+        fav, thr = recs.user_favourites(ui, ai, r, n_users, n_anime)
     torch.cuda.synchronize()
-    reps = 3
+    reps = 5
     t0 = time.perf_counter()
     for _ in range(reps):
         fav, thr = recs.user_favourites(ui, ai, r, n_users, n_anime)
@@ -406,7 +410,7 @@ def run_user_recs(cpu_baseline=True):
     torch.cuda.synchronize()
     dt_r = (time.perf_counter() - t0) / reps
     ww = (n_anime + 31) // 32
-    fav_bytes = 16 * n + 16 * n + (n_users * ww * 4)      # count+scatter pass, percentile + bit pass, bit rows written
+    fav_bytes = 16 * n + 16 * n + (n_users * ww * 4)      # count + CSR pass, percentile + bit pass, bit rows written
     rec_bytes = nq * (k_sim + 1) * ww * 4                 # the similar users' and the query's bit rows
     rec = {"value": nq / dt_r, "unit": "queries/s", "ms": dt_r * 1e3,
            "favourites": {"ms": dt_f * 1e3, "ratings_per_s": n / dt_f,
