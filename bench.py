@@ -198,6 +198,18 @@ def cpu_baseline_port(n_users, n_anime, batch, budget_s=12.0):
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense bf16/f16 MFMA peak (MI355X_MICROARCH.md)
 
 
+def pmc_traffic(name, kernels=None):
+    """HBM bytes from the committed PMC passes (profiles/r01_pmc_traffic_<name>.json): per-launch mean of one
+    kernel, or the sum over the listed kernels of (mean bytes x launches per call); None if unavailable."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % name)))["kernels"]
+        if isinstance(kernels, str):
+            return d[kernels]["total_bytes_per_launch"]
+        return sum(d[k]["total_bytes_per_launch"] * n for k, n in kernels.items())
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
 def run_cosine_topk(cpu_baseline=True):
     """BASELINE.json configs[3]: row-normalise + all-pairs cosine + top-k (queries/s).
     k = 10 is the reference's configured neighbour count (config/config.yaml:105 id_query_number,
@@ -302,7 +314,11 @@ def run_ingest(cpu_baseline=True):
            "roofline": {"kernel": "ingest pipeline (13 launches; k_ing_insert, the duplicate-row hash table, is "
                                   "55 % of it: one random 8-B CAS per row in a 2 GB table)",
                         "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_bytes}}
+                        "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes,
+                        "traffic": pmc_traffic("ingest", {"k_ing_alive": 1, "k_ing_insert": 1, "k_ing_count": 1,
+                                                          "k_ing_user_filter<true>": 1, "k_ing_compact": 1,
+                                                          "k_scan_reduce": 3, "k_scan_spine": 3, "k_scan_apply": 3,
+                                                          "k_enc_first": 2, "k_enc_flag": 2, "k_enc_emit": 2})}}
     if cpu_baseline:
         import pandas as pd
         from oracle import ingest_oracle
@@ -419,7 +435,7 @@ def run_user_recs(cpu_baseline=True):
                                        "frac": fav_bytes / dt_f / 1e9 / HBM_PEAK_GBS, "traffic": None}},
            "roofline": {"kernel": "k_user_recs (one workgroup per query: 11 bit rows of 2.25 KB -> LDS counts -> top-10)",
                         "bound": "hbm", "achieved": rec_bytes / dt_r / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": rec_bytes / dt_r / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+                        "frac": rec_bytes / dt_r / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("recs", "k_user_recs")}}
     if cpu_baseline:
         from oracle import recs_oracle
         nu_s = 2_000                                       # users 0..1999 of the same table
@@ -496,7 +512,7 @@ def run_predict_grid(cpu_baseline=True):
     rec = {"value": nq * n_a / dt, "unit": "ratings/s", "ms": dt * 1e3,
            "roofline": {"kernel": "k_predict_mfma (split-f16 MFMA + sigmoid head, fp32 grid written)", "bound": "hbm",
                         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                        "traffic": None}}
+                        "traffic": pmc_traffic("pgrid", "k_predict_mfma")}}
     if cpu_baseline:
         from oracle import c_oracle
         Un, An = U[:4096].cpu().numpy(), A.cpu().numpy()
