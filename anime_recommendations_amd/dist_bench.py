@@ -35,6 +35,42 @@ def main(args):
     dist.destroy_process_group()
 
 
+def _sharded_topk_leg(rank, world, dev):
+    """The second half of BASELINE.json's metric at N GPUs: the whole similar-users job — cosine top-10 of
+    all 350 000 users against all 350 000 keys — with the query rows sharded over the ranks (independent
+    units: no collective in the loop; each rank keeps its [nq/N, k] block).  Strong scaling of a fixed job.
+    Never fails the training bench: errors are reported in the line."""
+    import torch
+    import torch.distributed as dist
+    try:
+        from . import ops
+        from .dist_infer import shard_bounds
+        n, nq, k = 350_000, 350_000, 10
+        g = torch.Generator(device=dev)
+        g.manual_seed(7)
+        W = torch.randn(n, 128, generator=g, device=dev) * 0.05
+        Wh = ops.rownorm(W)
+        lo, hi = shard_bounds(nq, rank, world)
+        q = torch.arange(lo, hi, dtype=torch.int32, device=dev)
+        ops.cosine_topk_mfma(Wh, q, k)
+        torch.cuda.synchronize()
+        dist.barrier()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            idx, sc, nfb = ops.cosine_topk_mfma(Wh, q, k)      # batches of <= 65 536 queries inside
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        del W, Wh
+        torch.cuda.empty_cache()
+        return {"value": nq / float(dt[0]), "unit": "queries/s", "ms": float(dt[0]) * 1e3, "n_gpus": world,
+                "queries_per_rank": hi - lo, "scaling": "strong"}
+    except Exception as exc:                                   # noqa: BLE001 - reported, never raised
+        return {"error": "%s: %s" % (type(exc).__name__, exc)}
+
+
 def _run(args, rank, world, dev):
     import torch
     import torch.distributed as dist
@@ -107,6 +143,7 @@ def _run(args, rank, world, dev):
     rows = eng.n_local + n_anime
     adam_bytes = bench.ADAM_BYTES_PER_ELEM * rows * 128
     adam_gbs = adam_bytes / (kern_ms["adam"] * 1e-3) / 1e9
+    topk = _sharded_topk_leg(rank, world, dev)
     if rank == 0:
         line = {
             "metric": "training_ratings_per_sec", "value": K * B * world / dt, "unit": "ratings/s",
@@ -126,6 +163,7 @@ def _run(args, rank, world, dev):
             "cpu_baseline": None,
             "kernels_ms": kern_ms,
             "final_loss": float(rec["last_loss"]),
+            "also": {"cosine_topk_users_350k_allpairs_top10": topk},
         }
         print(json.dumps(line), flush=True)
     eng.close()

@@ -266,6 +266,25 @@ def run_cosine_topk(cpu_baseline=True):
             rec["cpu_baseline"] = {"value": nqc / dtc, "unit": "queries/s", "cores": c_oracle.max_threads(),
                                    "kind": "port", "sample": "%d queries, plain-C dot + top-%d per query" % (nqc, k)}
         out[name] = rec
+        if (n, nq, k) == (350_000, 65_536, 10):
+            # the whole similar-users job (every user a query: 5.3 such slices); bench.py --gpus N reports the
+            # same job sharded over N ranks (dist_bench.py)
+            qa = torch.arange(n, dtype=torch.int32, device="cuda")
+            ops.cosine_topk_mfma(Wh, qa, k)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                ops.cosine_topk_mfma(Wh, qa, k)
+            torch.cuda.synchronize()
+            dta = (time.perf_counter() - t0) / 3
+            out["users_350k_allpairs_top10"] = {"value": n / dta, "unit": "queries/s", "ms": dta * 1e3, "k": k,
+                                                "pipeline_tflops": 2.0 * n * n * 128 / dta / 1e12,
+                                                "roofline": {"kernel": "k_cand, 6 query slices", "bound": "mfma",
+                                                             "achieved": 2.0 * n * n * 128 / dta / 1e12,
+                                                             "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                             "frac": 2.0 * n * n * 128 / dta / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                                                             "traffic": None}}
+            del qa
         del W, Wh, q
         torch.cuda.empty_cache()
     return out
