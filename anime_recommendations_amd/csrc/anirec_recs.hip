@@ -247,30 +247,39 @@ __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
   const int qu = a.query[q];
   const int n_pad = a.wwords * 32;
   for (int w = tid; w < a.wwords; w += 256) {
-    uint32_t cnt[32];
-    uint32_t best[32];
-#pragma unroll
-    for (int b = 0; b < 32; ++b) {
-      cnt[b] = 0;
-      best[b] = 63;
-    }
+    // Bit-sliced (vertical) counters: plane p of `cp` holds bit p of the count of each of the word's 32
+    // anime, so one similar user's 32 favourite bits are added to all 32 counts with a 6-step carry chain;
+    // `bp` holds, the same way, the rank of the FIRST similar user holding the anime (they come best first).
+    uint32_t cp[6] = {0u, 0u, 0u, 0u, 0u, 0u}, bp[6] = {0u, 0u, 0u, 0u, 0u, 0u}, seen = 0u;
     for (int j = 0; j < a.k_sim; ++j) {
       const int su = a.sim[(size_t)q * a.k_sim + j];
       if (su < 0 || su >= a.n_users) continue;
-      uint32_t bits = a.fav[(size_t)su * a.wwords + w];
-      while (bits) {
-        const int b = __ffs((int)bits) - 1;
-        bits &= bits - 1;
-        if (cnt[b] == 0) best[b] = j;  // similar users come best first: the first holder is the best rank
-        cnt[b] += 1;
+      const uint32_t bits = a.fav[(size_t)su * a.wwords + w];
+      uint32_t carry = bits;
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        const uint32_t t = cp[p] & carry;
+        cp[p] ^= carry;
+        carry = t;
       }
+      const uint32_t fresh = bits & ~seen;
+      seen |= bits;
+#pragma unroll
+      for (int p = 0; p < 6; ++p)
+        if ((j >> p) & 1) bp[p] |= fresh;
     }
     const uint32_t own = (qu >= 0 && qu < a.n_users) ? a.fav[(size_t)qu * a.wwords + w] : 0u;
+    const uint32_t ok = seen & ~own;
 #pragma unroll
     for (int b = 0; b < 32; ++b) {
       const int an = w * 32 + b;
-      const bool ok = cnt[b] != 0 && !((own >> b) & 1u) && an < a.n_anime;
-      sm[an] = ok ? (uint16_t)((cnt[b] << 6) | (63u - best[b])) : (uint16_t)0;
+      uint32_t cnt = 0, best = 0;
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        cnt |= ((cp[p] >> b) & 1u) << p;
+        best |= ((bp[p] >> b) & 1u) << p;
+      }
+      sm[an] = (((ok >> b) & 1u) && an < a.n_anime) ? (uint16_t)((cnt << 6) | (63u - best)) : (uint16_t)0;
     }
   }
   for (int c = tid; c <= kRecsMaxSim; c += 256) {
