@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libanirec.so")
+LIB_PATH = os.environ.get("ANIREC_LIB_PATH") or os.path.join(_PKG, "libanirec.so")   # override: A/B of two builds on one box
 
 DIM = 128
 MAX_BATCH = 16384
