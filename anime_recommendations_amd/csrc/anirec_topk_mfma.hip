@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64) void k_refresh(CandArgs a) {
 // kWaves = 8 (256 query rows per workgroup, one workgroup per CU) halves the L2 -> LDS key traffic per
 // MFMA and is used when the queries fill the chip that way; kWaves = 4 (two workgroups per CU) otherwise.
 // kMask: a candidate is dropped at append time when its bit in the query's own mask row is set (the
-// "already watched" set of model_recs); the mask words are prefetched a tile ahead into registers.
+// "already watched" set of model_recs); the mask words reach a wave-private LDS image by LDS-DMA two tiles ahead.
 template <int kDbg, int kWaves, bool kMask = false>  // kDbg 0: product; 1: no filter (timing only); 2: count appends; 4: stamps
 __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
   constexpr int kBM = 32 * kWaves;
@@ -252,6 +252,39 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
   const int nt = a.tile1 - a.tile0;
   dma_tile(a.tile0, 0);
   if (nt > 1) dma_tile(a.tile0 + 1, 1);
+  // kMask: the four 32-key mask words of each of the wave's 32 query rows travel global -> LDS by LDS-DMA as
+  // well (two 256-B pieces per tile and wave into a wave-private [3][32][4] image, two tiles ahead), so they
+  // are covered by the same hand-placed vmcnt waits as the key tiles.  (Plain loads into registers made the
+  // compiler wait vmcnt(0) at the end of every tile — for the key-tile DMA issued half a tile earlier too.)
+  extern __shared__ uint32_t mask_lds[];
+  uint32_t *const mk_l = mask_lds + w * (3 * 128);
+  uint32_t mk_voff[2] = {0u, 0u};
+  uint32_t mk_base = 0;
+  if (kMask) {
+    mk_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)mask_lds + (uint32_t)wu * (3u * 512u);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int rg = q0 + 32 * w + 16 * j + (lane >> 2);
+      if (rg >= a.nq) rg = a.nq - 1;  // rows past the end never produce candidates: any valid address will do
+      mk_voff[j] = (uint32_t)rg * (uint32_t)a.wwords;
+    }
+  }
+  auto dma_mask = [&](int t, int slot) {
+    int wd = t * (kBN / 32) + (lane & 3);
+    if (wd >= a.wwords) wd = a.wwords - 1;  // words past the end belong to NaN padding keys
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t voff = (mk_voff[j] + (uint32_t)wd) * 4u;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
+                   :
+                   : "v"(voff), "s"(a.watched), "s"(mk_base + (uint32_t)slot * 512u + 256u * j)
+                   : "memory", "m0");
+    }
+  };
+  if (kMask) {
+    dma_mask(a.tile0, 0);
+    if (nt > 1) dma_mask(a.tile0 + 1, 1);
+  }
 
   // Accumulator register i of block (rb, nb) belongs to query row 16 rb + 4 gq + i of the wave's 32
   // rows: the rows are private to the wave, so their thresholds and buffer counts live in registers
@@ -309,7 +342,7 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
   auto mma1 = [&](Acc &x, int rb, int nb, int kk) {
     x.c[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[rb][kk], bv[nb][kk], kk == 0 ? nthr[rb] : x.c[rb][nb], 0, 0, 0);
   };
-  auto stage_fn = [&](const Acc &cur, Acc &nxt, int key0, int fbuf, int fcb, uint32_t mword) {
+  auto stage_fn = [&](const Acc &cur, Acc &nxt, int key0, int fbuf, int fcb, int moff) {
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {  // quarter qd: MFMA step kk = qd of the next block, filter (rb, nb) of this one
       const int rb = qd >> 1, nb = qd & 1;
@@ -342,8 +375,8 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           bool hit = cv[i] >= 0.f;
-          if (kMask) {  // the row's 32 mask bits of this key block sit in lane (row) of the prefetched word
-            const uint32_t wbits = (uint32_t)__shfl((int)mword, 16 * rb + 4 * gq + i, 64);
+          if (kMask) {  // the row's 32 mask bits of this key block: one word of the wave's LDS mask image
+            const uint32_t wbits = mk_l[moff + 4 * (16 * rb + 4 * gq + i)];
             hit = hit && ((wbits >> (16 * nb + c16)) & 1u) == 0u;
           }
           const unsigned long long mk = __ballot(hit);
@@ -370,31 +403,14 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) fetch(kk, 0, 1);
 
-  // kMask: lane l < 32 holds the four 32-key mask words of query row l of the wave for the current
-  // tile (one 16-B load per row and tile, prefetched a tile ahead), so the append path tests a bit
-  // after one cross-lane read instead of a dependent global load.
-  u32x4 mcur = {0u, 0u, 0u, 0u}, mnext = {0u, 0u, 0u, 0u};
-  auto load_mask = [&](int t) {
-    u32x4 v = {0u, 0u, 0u, 0u};
-    const int rl = q0 + 32 * w + (lane & 31);
-    if (rl < a.nq) {
-      const uint32_t *src = a.watched + (size_t)rl * a.wwords;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int wd = t * (kBN / 32) + j;
-        if (wd < a.wwords) v[j] = src[wd];
-      }
-    }
-    return v;
-  };
-  if (kMask) mcur = load_mask(a.tile0);
   unsigned long long dbg_store = 0, dbg_barrier = 0, dbg_t0 = 0;
   if (kDbg == 4) dbg_t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < nt; ++it) {
     const int buf = it & 1;
     const int key0 = (a.tile0 + it) * kBN;
-    stage_fn(acc0, acc1, key0, buf, 2, mcur[0]);       // filter block 0 | MFMA block 1 | fetch block 2
-    stage_fn(acc1, acc0, key0 + 32, buf, 3, mcur[1]);  // filter block 1 | MFMA block 2 | fetch block 3
+    const int ms = (it % 3) * 128;                     // this tile's slot in the wave's LDS mask image
+    stage_fn(acc0, acc1, key0, buf, 2, ms + 0);        // filter block 0 | MFMA block 1 | fetch block 2
+    stage_fn(acc1, acc0, key0 + 32, buf, 3, ms + 1);   // filter block 1 | MFMA block 2 | fetch block 3
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
     if (kDbg == 4) ts0 = __builtin_amdgcn_s_memtime();
     // tile it+1 was sent to the other buffer one tile ago; its DMA (and this wave's candidate stores,
@@ -412,12 +428,11 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
     }
     // this tile's buffer was last read (fetched) before the barrier: refill it with tile it+2, in
     // flight for a whole tile
-    if (kMask && it + 1 < nt) mnext = load_mask(a.tile0 + it + 1);
+    if (kMask && it + 2 < nt) dma_mask(a.tile0 + it + 2, (it + 2) % 3);  // its slot was tile it-1's
     if (it + 2 < nt) dma_tile(a.tile0 + it + 2, buf);
     // on the last tile the "next tile" blocks are stale LDS: computed and thrown away
-    stage_fn(acc0, acc1, key0 + 64, buf ^ 1, 0, mcur[2]);  // filter block 2 | MFMA block 3 | fetch next tile's block 0
-    stage_fn(acc1, acc0, key0 + 96, buf ^ 1, 1, mcur[3]);  // filter block 3 | MFMA next block 0 | fetch next block 1
-    if (kMask) mcur = mnext;
+    stage_fn(acc0, acc1, key0 + 64, buf ^ 1, 0, ms + 2);  // filter block 2 | MFMA block 3 | fetch next tile's block 0
+    stage_fn(acc1, acc0, key0 + 96, buf ^ 1, 1, ms + 3);  // filter block 3 | MFMA next block 0 | fetch next block 1
   }
   if (kDbg == 4 && lane == 0) {  // in-kernel stamps (diagnostic build only): cycles per wave
     unsigned long long *d = a.dbg + 4 * (size_t)(blockIdx.x * kWaves + w);
@@ -640,6 +655,16 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
   const dim3 grid(wide ? (nq + 255) / 256 : (nq + 127) / 128);
   const dim3 block(wide ? 512 : 256);
   int n_launch = 0;
+  if (masked) {  // 64 KB of key tiles (static) + the mask images (dynamic) exceed the default 64 KB cap
+    static bool attr_set = false;
+    if (!attr_set) {
+      ANIREC_HIP_CHECK(hipFuncSetAttribute((const void *)k_cand<0, 8, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 1024));
+      ANIREC_HIP_CHECK(hipFuncSetAttribute((const void *)k_cand<0, 4, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 1024));
+      attr_set = true;
+    }
+  }
   std::vector<hipEvent_t> timed;  // event pairs around the k_cand launches (timing mode only)
   const char *gp = getenv("ANIREC_TOPK_GROWTH");
   const int growth_pct = gp ? atoi(gp) : 100;
@@ -652,12 +677,13 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
     const int t1 = t0 + step < ntiles ? t0 + step : ntiles;
     ca.tile0 = t0;
     ca.tile1 = t1;
-#define ANIREC_LAUNCH_CAND(D, M)                                           \
-  do {                                                                     \
-    if (wide)                                                              \
-      hipLaunchKernelGGL((k_cand<D, 8, M>), grid, block, 0, s, ca);        \
-    else                                                                   \
-      hipLaunchKernelGGL((k_cand<D, 4, M>), grid, block, 0, s, ca);        \
+#define ANIREC_LAUNCH_CAND(D, M)                                                                    \
+  do {                                                                                              \
+    const size_t shm = (M) ? (size_t)(wide ? 8 : 4) * 3 * 512 : 0;  /* the waves' LDS mask images */   \
+    if (wide)                                                                                       \
+      hipLaunchKernelGGL((k_cand<D, 8, M>), grid, block, shm, s, ca);                               \
+    else                                                                                            \
+      hipLaunchKernelGGL((k_cand<D, 4, M>), grid, block, shm, s, ca);                               \
   } while (0)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (g_time_cand) {
@@ -845,6 +871,7 @@ int anirec_predict_topk_mfma(const float *U, const float *A, int32_t n_anime, co
   if (n_users == 0) return ANIREC_OK;
   if (workspace_bytes < anirec_predict_topk_mfma_workspace_bytes(n_anime, n_users)) return ANIREC_EWORKSPACE;
   if ((size_t)n_users * kCap * 8 >= ((size_t)1 << 32)) return ANIREC_EINVAL;  // batch the users
+  if ((size_t)n_users * ((n_anime + 31) / 32) >= ((size_t)1 << 30)) return ANIREC_EINVAL;  // 32-bit mask offsets
   hipStream_t s = (hipStream_t)stream;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   char *p = (char *)workspace;
