@@ -666,8 +666,11 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
     }
   }
   std::vector<hipEvent_t> timed;  // event pairs around the k_cand launches (timing mode only)
+  // each super-step sees growth_pct % of the keys seen so far: a row gains about k_eff * growth candidates per
+  // step, which must fit the buffer next to the ~2 k_eff it already holds — tripling for small k (fewer
+  // launches and refreshes), doubling otherwise
   const char *gp = getenv("ANIREC_TOPK_GROWTH");
-  const int growth_pct = gp ? atoi(gp) : 100;
+  const int growth_pct = gp ? atoi(gp) : (ca.k_eff <= 32 ? 200 : 100);
   // the first super-step runs without a threshold and appends every key it sees: keep it as short as
   // the k-th-best estimate allows (>= 4 k_eff keys), at most what the buffer holds
   int first = (4 * ca.k_eff + kBN - 1) / kBN;
