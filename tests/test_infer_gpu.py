@@ -254,3 +254,37 @@ def test_cosine_topk_few_queries_sliced_select_keeps_the_tie_rule():
     # the duplicates of the query are its nearest neighbours, in ascending index order
     idx, _ = ops.cosine_topk(Wh, [7], 10)
     assert idx.cpu().numpy()[0][:5].tolist() == [2343, 2344, 2400, 70_000, 149_999]
+
+
+@pytest.mark.parametrize("waves", ["4", "8"])
+def test_mfma_paths_on_random_odd_shapes(waves, monkeypatch):
+    """Both workgroup shapes of k_cand (128- and 256-row) on sizes that are multiples of nothing: key
+    tables ending inside a tile, query counts ending inside a workgroup / a wave, k from 1 to 127, key
+    masks, and the masked predict variant — always identical to the exact kernels."""
+    from anime_recommendations_amd import ops
+    monkeypatch.setenv("ANIREC_TOPK_WAVES", waves)
+    rng = np.random.default_rng(100 + int(waves))
+    for trial in range(10):
+        n = int(rng.integers(130, 9000))
+        nq = int(rng.integers(1, 700))
+        k = int(rng.choice([1, 2, 10, 37, 100, 127]))
+        W = rng.normal(0, 0.05, (n, 128)).astype(np.float32)
+        W[rng.integers(0, n, 3)] = W[0]                      # a few exact ties
+        Wh = ops.rownorm(torch.from_numpy(W))
+        q = rng.integers(0, n, nq).astype(np.int32)
+        keep = (rng.random(n) > 0.3).astype(np.uint8) if trial % 2 else None
+        ex = bool(trial % 3)
+        ei, es = ops.cosine_topk(Wh, q, k, exclude_self=ex, keep=keep)
+        mi, ms, _ = ops.cosine_topk_mfma(Wh, q, k, exclude_self=ex, keep=keep)
+        assert torch.equal(mi, ei), (trial, n, nq, k)
+        assert torch.equal(torch.nan_to_num(ms, nan=-9.0), torch.nan_to_num(es, nan=-9.0)), (trial, n, nq, k)
+        # masked predict variant on the same odd shapes (keys = n "anime", queries = nq "users")
+        if k <= 100:
+            U = torch.from_numpy(rng.normal(0, 0.05, (max(nq, 2), 128)).astype(np.float32)).cuda()
+            head = dict(w=1.1, b=0.05, gamma=0.95, beta=-0.1, mov_mean=0.02, mov_var=0.6)
+            users = np.arange(nq, dtype=np.int32)
+            _, bits = _watched_bits(rng, nq, n, 0.25)
+            pe = ops.predict_topk(U, torch.from_numpy(W).cuda(), head, users, k, bits)
+            pm = ops.predict_topk_mfma(U, torch.from_numpy(W).cuda(), head, users, k, bits)
+            assert torch.equal(pm[0], pe[0]), (trial, n, nq, k)
+            assert torch.equal(torch.nan_to_num(pm[1], nan=-9.0), torch.nan_to_num(pe[1], nan=-9.0))
