@@ -7,12 +7,12 @@ from anime_recommendations_amd import data, trainer
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "s7m"
 n_users, n_anime = bench.WORKLOADS[wl]
-n = 7_000_000 if wl == "s7m" else 30_000_000
+n = int(sys.argv[2]) if len(sys.argv) > 2 else (7_000_000 if wl == "s7m" else 30_000_000)
 ui, ai, t = bench.synth_ratings(n_users, n_anime, n, torch.device("cuda"))
 table = data.RatingTable(ui.cpu().numpy().astype(np.int64), ai.cpu().numpy().astype(np.int64),
                          t.cpu().numpy().astype(np.float64), np.arange(n_users), np.arange(n_anime))
 del ui, ai, t
-cfg = trainer.FitConfig(epochs=4, batch_size=10_000, test_size=10_000, verbose=1)
+cfg = trainer.FitConfig(epochs=int(sys.argv[3]) if len(sys.argv) > 3 else 4, batch_size=10_000, test_size=10_000, verbose=1)
 marks = []
 def log(msg):
     marks.append(time.perf_counter()); print(msg)
