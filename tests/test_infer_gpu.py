@@ -288,3 +288,24 @@ def test_mfma_paths_on_random_odd_shapes(waves, monkeypatch):
             pm = ops.predict_topk_mfma(U, torch.from_numpy(W).cuda(), head, users, k, bits)
             assert torch.equal(pm[0], pe[0]), (trial, n, nq, k)
             assert torch.equal(torch.nan_to_num(pm[1], nan=-9.0), torch.nan_to_num(pe[1], nan=-9.0))
+
+
+def test_mfma_paths_on_tiny_tables():
+    """Tables smaller than one key tile / one wave, k larger than the table: -1 / NaN padding identical to the
+    exact kernels (rows with fewer than k candidates are flagged and re-run through them)."""
+    from anime_recommendations_amd import ops
+    rng = np.random.default_rng(77)
+    for n, k in ((2, 1), (7, 10), (33, 40), (127, 127)):
+        W = rng.normal(0, 0.05, (n, 128)).astype(np.float32)
+        Wh = ops.rownorm(torch.from_numpy(W))
+        q = np.arange(n, dtype=np.int32)
+        ei, es = ops.cosine_topk(Wh, q, k)
+        mi, ms, nfb = ops.cosine_topk_mfma(Wh, q, k)
+        assert torch.equal(mi, ei), (n, k)
+        assert torch.equal(torch.nan_to_num(ms, nan=-9.0), torch.nan_to_num(es, nan=-9.0)), (n, k)
+        U = torch.from_numpy(rng.normal(0, 0.05, (n, 128)).astype(np.float32)).cuda()
+        head = dict(w=1.1, b=0.05, gamma=0.95, beta=-0.1, mov_mean=0.02, mov_var=0.6)
+        pe = ops.predict_topk(U, torch.from_numpy(W).cuda(), head, q, min(k, 100), None)
+        pm = ops.predict_topk_mfma(U, torch.from_numpy(W).cuda(), head, q, min(k, 100), None)
+        assert torch.equal(pm[0], pe[0]), (n, k)
+        assert torch.equal(torch.nan_to_num(pm[1], nan=-9.0), torch.nan_to_num(pe[1], nan=-9.0)), (n, k)
