@@ -117,6 +117,7 @@ PROTOTYPES = {
     "anirec_ingest_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "anirec_ingest_preprocess": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(IngestOpts), _vp, _vp, _vp,
                                            _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "anirec_ingest_half_columns": (C.c_int, [_vp, _vp, _i64, C.POINTER(IngestOpts), _vp, _vp, _vp, _sz, _vp]),
     "anirec_ingest_encode_workspace_bytes": (_sz, [_i64, _i32]),
     "anirec_ingest_encode": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }

@@ -83,24 +83,41 @@ def load_synopses(path):
 
 
 def all_genres(anime_df):
-    """get_genres (similar_anime.py:174-192): every genre token, multi-word genres rejoined."""
-    tokens = set()
-    for g in anime_df["Genres"].dropna().unique():
-        tokens.update(x.strip() for x in str(g).split(","))
-    tokens.discard("")
-    return sorted(tokens | {"None"})
+    """get_genres (similar_anime.py:174-192): the text of the list of distinct Genres cells is split on
+    whitespace, every token stripped of non-alphanumerics; the fragments of the three multi-word genres
+    (and 'nan') are dropped and 'Slice of Life', 'Super Power', 'Martial Arts', 'None' appended — so, as in
+    the reference, any OTHER multi-word genre ("Shounen Ai") is only known by its fragments."""
+    cells = anime_df["Genres"].unique().tolist()
+    tokens = sorted({re.sub(r"[\W_]", "", t) for t in str(cells).split()})
+    fragments = {"Slice", "of", "Life", "Martial", "Arts", "Super", "Power", "nan"}
+    return sorted(t for t in tokens + ["Slice of Life", "Super Power", "Martial Arts", "None"] if t not in fragments)
 
 
 def genre_mask(genres_col, wanted):
     """by_genre (similar_anime.py:279-340): keep rows whose Genres contain ANY of the (three)
-    wanted genres, compared on cleaned, lower-cased, space-free text; 'None' entries ignored."""
+    wanted genres; 'None' entries ignored.  The wanted genres are clean()ed, the column text is only
+    lower-cased with spaces removed (:307-317) — so, as in the reference, a genre whose name holds
+    punctuation ("Sci-Fi" -> "scifi" vs "sci-fi") matches nothing
+    (tests/golden/ref_fn/genres.json holds the reference function's own outputs)."""
     wanted = [w for w in clean(list(wanted)) if w != "none"]
     col = [str(g).lower().replace(" ", "") for g in genres_col]
-    col = [re.sub(r"[^\w,]", "", c) for c in col]
     m = np.zeros(len(col), bool)
     for w in wanted:
-        m |= np.array([w in c for c in col])
+        m |= np.array([w in c for c in col], dtype=bool)
     return m
+
+
+def _topk_count(asked, what):
+    """The reference returns as many rows as asked for (Frame[:count]); the fused top-k kernels hold at
+    most MAX_TOPK rows per query, so a larger request is an error here, never a silent truncation."""
+    from ._lib import MAX_TOPK
+    k = int(asked)
+    if k < 1:
+        raise ValueError("%s must be >= 1 (got %d)" % (what, k))
+    if k > MAX_TOPK:
+        raise ValueError("%s = %d exceeds the %d rows the GPU top-k kernels return per query "
+                         "(ANIREC_MAX_TOPK)" % (what, k, MAX_TOPK))
+    return k
 
 
 def check_genres(wanted, anime_df):
@@ -189,7 +206,7 @@ def similar_anime_frame(A, anime_ids, anime_df, syn_df, name, count, types=None,
         check_genres(genres, anime_df)
         keep &= genre_mask(meta["Genres"], genres)
     Wh = ops.rownorm(torch.as_tensor(A))
-    k = min(int(count), 128)
+    k = _topk_count(count, "a_query_number")
     idx, sim = ops.cosine_topk(Wh, [q], k, exclude_self=True, keep=keep.astype(np.uint8))
     idx, sim = idx.cpu().numpy()[0], sim.cpu().numpy()[0]
     ok = idx >= 0
@@ -235,7 +252,7 @@ def similar_users_frame(U, user_ids, df, anime_df, user_id, n_users, num_faves, 
     if len(pos) == 0:
         raise ValueError("user id %r has no embedding row" % (user_id,))
     Uh = ops.rownorm(torch.as_tensor(U))
-    k = min(int(n_users), 128)
+    k = _topk_count(n_users, "id_query_number")
     idx, sim = ops.cosine_topk(Uh, [int(pos[0])], k, exclude_self=True)
     idx, sim = idx.cpu().numpy()[0], sim.cpu().numpy()[0]
     ok = idx >= 0
@@ -273,7 +290,7 @@ def model_recs_frame(U, A, head, user_ids, anime_ids, df, anime_df, syn_df, user
     nz = np.nonzero(blocked)[0]
     np.bitwise_or.at(bits[0], nz >> 5, (np.uint32(1) << (nz & 31).astype(np.uint32)))
     tU, tA = torch.as_tensor(U).cuda(), torch.as_tensor(A).cuda()
-    k = min(int(n_recs), 128)
+    k = _topk_count(n_recs, "model_num_recs")
     idx, p = ops.predict_topk(tU, tA, head, [int(pos[0])], k, bits.view(np.int32))
     idx, p = idx.cpu().numpy()[0], p.cpu().numpy()[0]
     ok = idx >= 0

@@ -301,6 +301,18 @@ __global__ __launch_bounds__(256) void k_ing_compact(IngestCols c, int64_t n, co
   }
 }
 
+// the two columns drop_half_watched leaves in the frame (preprocess.py:99-100), for the surviving rows
+__global__ __launch_bounds__(256) void k_ing_half_columns(const int32_t *anime, const int64_t *n_out, const int32_t *mx,
+                                                          int32_t *max_eps, double *half_eps) {
+  const int64_t m = *n_out;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+    const int32_t v = mx[anime[i]];
+    max_eps[i] = v;
+    half_eps[i] = v == 1 ? 1.0 : (double)v * .5;
+  }
+}
+
 // ---- Series.unique() encoding: dense index = rank of the id's first appearance ----
 __global__ __launch_bounds__(256) void k_enc_first(const int32_t *id, int64_t n, int bound, int32_t *first, int32_t *err) {
   const int lane = lane_id();
@@ -442,6 +454,24 @@ int anirec_ingest_preprocess(const int32_t *user_id, const int32_t *anime_id, co
   if (rc) return rc;
   const IngestOut o{out_user_id, out_anime_id, out_rating, out_status, out_episodes};
   hipLaunchKernelGGL(k_ing_compact, dim3(g), dim3(256), 0, s, c, n, keep, pos, mm, o);
+  return (int)hipGetLastError();
+}
+
+int anirec_ingest_half_columns(const int32_t *out_anime_id, const int64_t *n_out, int64_t n,
+                               const anirec_ingest_opts *opts, int32_t *out_max_eps, double *out_half_eps,
+                               const void *workspace, size_t workspace_bytes, void *stream) {
+  if (!out_anime_id || !n_out || !opts || !out_max_eps || !out_half_eps || !workspace) return ANIREC_EINVAL;
+  if (n < 1 || n >= ((int64_t)1 << 30) || opts->user_id_bound < 1 || opts->anime_id_bound < 1) return ANIREC_EINVAL;
+  if (!opts->drop_half_watched) return ANIREC_EINVAL;  // the per-anime maxima only exist after that pass
+  if (workspace_bytes < anirec_ingest_workspace_bytes(n, opts->user_id_bound, opts->anime_id_bound))
+    return ANIREC_EWORKSPACE;
+  // same carve as anirec_ingest_preprocess: the per-anime maxima sit behind the user counts
+  const size_t np = pad_tile(n);
+  const char *p = (const char *)workspace;
+  p += 2 * al256(np) + al256(np * 4) + al256(np / kScanTile * 4) + al256((size_t)table_slots(n) * 8) +
+       al256((size_t)opts->user_id_bound * 4);
+  hipLaunchKernelGGL(k_ing_half_columns, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out_anime_id, n_out,
+                     (const int32_t *)p, out_max_eps, out_half_eps);
   return (int)hipGetLastError();
 }
 

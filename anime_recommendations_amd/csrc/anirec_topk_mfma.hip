@@ -67,8 +67,10 @@ __device__ __forceinline__ float key2f(uint32_t u) {
 // Key rows excluded by the caller's mask become NaN rows: their scores are NaN, which never compares
 // >= 0 and is ignored by v_max — the filter needs no per-key test (and no load) in the hot loop.
 // rows n .. n_pad-1 of the output are NaN rows (key-tile padding).
+// unnorm: set to 1 when a finite row is not unit-norm (| sum x^2 - 1 | > 1e-3): the error window of the MFMA
+// scores (kEpsMfma) is proven for unit vectors only, so k_rerank then sends every query to the exact path.
 __global__ __launch_bounds__(256) void k_to_f16(const float *W, const int32_t *rows, int n, int n_pad,
-                                                const uint8_t *keep, int zero_nan, _Float16 *out) {
+                                                const uint8_t *keep, int zero_nan, _Float16 *out, int32_t *unnorm) {
   const int l = threadIdx.x & 31;
   const int nhw = gridDim.x * 8;
   for (int r = blockIdx.x * 8 + (threadIdx.x >> 5); r < n_pad; r += nhw) {
@@ -80,7 +82,10 @@ __global__ __launch_bounds__(256) void k_to_f16(const float *W, const int32_t *r
     const float4 x = reinterpret_cast<const float4 *>(W)[(size_t)src * kRowVec + l];
     _Float16 o[4] = {(_Float16)x.x, (_Float16)x.y, (_Float16)x.z, (_Float16)x.w};
     uint2 v = *reinterpret_cast<uint2 *>(o);
-    if (keep && !keep[r]) v = make_uint2(0x7E007E00u, 0x7E007E00u);
+    const bool masked = keep && !keep[r];
+    if (masked) v = make_uint2(0x7E007E00u, 0x7E007E00u);
+    const float ss = halfwave_sum(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w);
+    if (!masked && l == 0 && fabsf(ss - 1.0f) > 1e-3f) *unnorm = 1;  // NaN rows compare false: handled by the NaN rules
     // a NaN QUERY row would poison the max over the accumulator registers it shares with other
     // query rows: it is zeroed here and flagged by k_rerank (its exact scores are NaN anyway)
     if (zero_nan && (x.x != x.x || x.y != x.y || x.z != x.z || x.w != x.w)) v = make_uint2(0u, 0u);
@@ -455,8 +460,9 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
   }
 }
 
-__global__ void k_init_rows(int32_t *cnt, float *theta, int32_t *flags, int nq) {
+__global__ void k_init_rows(int32_t *cnt, float *theta, int32_t *flags, int nq, int32_t *unnorm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && unnorm) *unnorm = 0;
   if (i < nq) {
     cnt[i] = 0;
     theta[i] = kThetaInit;
@@ -480,6 +486,7 @@ struct RerankArgs {
   int32_t *out_idx;        // [nq][k]
   float *out_score;        // [nq][k]
   float hs, hb, sign;      // kPredict: rating = sigmoid(c * hs + hb); MFMA scores are sign * c
+  const int32_t *unnorm;   // cosine path: non-zero when some row was not unit-norm (window unproven) -> flags bit 2
 };
 
 constexpr int kMaxSurv = 256;
@@ -519,6 +526,8 @@ __global__ __launch_bounds__(64) void k_rerank(RerankArgs a) {
     u[j] = e < c ? f2key(sc[j]) : 0u;
   }
   bool bad = (a.flags[row] & 1) != 0;
+  const bool unnorm = a.unnorm != nullptr && a.unnorm[0] != 0;
+  if (unnorm) bad = true;
   if (__ballot(qs[lane] != qs[lane] || qs[lane + 64] != qs[lane + 64])) bad = true;  // NaN query row
   const int kk = min(a.k_eff, a.n);
   if (c < kk) bad = true;
@@ -550,7 +559,7 @@ __global__ __launch_bounds__(64) void k_rerank(RerankArgs a) {
   if (ns > kMaxSurv) bad = true;
   __syncthreads();
   if (bad) {
-    if (lane == 0) a.flags[row] |= 2;
+    if (lane == 0) a.flags[row] |= unnorm ? 6 : 2;
     for (int i = lane; i < a.k; i += 64) {
       a.out_idx[(size_t)row * a.k + i] = -1;
       a.out_score[(size_t)row * a.k + i] = __uint_as_float(0x7FC00000u);
@@ -799,10 +808,11 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
   int b1 = (n + 7) / 8, b2 = (nq + 7) / 8;
   if (b1 > 8192) b1 = 8192;
   if (b2 > 8192) b2 = 8192;
-  hipLaunchKernelGGL(k_to_f16, dim3(b1), dim3(256), 0, s, What, nullptr, n, (int)padded_keys(n), keep, 0, Wb);
-  hipLaunchKernelGGL(k_to_f16, dim3(b2), dim3(256), 0, s, What, queries, nq, nq, nullptr, 1, Qb);
+  int32_t *unnorm = (int32_t *)(p + 64);  // inside the 256 spare bytes at the end of the workspace
+  hipLaunchKernelGGL(k_init_rows, dim3((nq + 255) / 256), dim3(256), 0, s, cnt, theta, flags_out, nq, unnorm);
+  hipLaunchKernelGGL(k_to_f16, dim3(b1), dim3(256), 0, s, What, nullptr, n, (int)padded_keys(n), keep, 0, Wb, unnorm);
+  hipLaunchKernelGGL(k_to_f16, dim3(b2), dim3(256), 0, s, What, queries, nq, nq, nullptr, 1, Qb, unnorm);
   ANIREC_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(k_init_rows, dim3((nq + 255) / 256), dim3(256), 0, s, cnt, theta, flags_out, nq);
   CandArgs ca;
   ca.Qb = (const uint4 *)Qb;
   ca.Wb = (const uint4 *)Wb;
@@ -850,6 +860,7 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
   // self exclusion is by key index; without it the query index is only used to fetch the row
   ra.hs = ra.hb = 0.f;
   ra.sign = 1.f;
+  ra.unnorm = unnorm;
   hipLaunchKernelGGL(k_rerank<false>, dim3(nq), dim3(64), 0, s, ra);
   return (int)hipGetLastError();
 }
@@ -900,7 +911,7 @@ int anirec_predict_topk_mfma(const float *U, const float *A, int32_t n_anime, co
   if (b2 > 8192) b2 = 8192;
   hipLaunchKernelGGL(k_norm_f16, dim3(b1), dim3(256), 0, s, A, nullptr, n_anime, (int)padded_keys(n_anime), 1.0f, Ah, Wb);
   hipLaunchKernelGGL(k_norm_f16, dim3(b2), dim3(256), 0, s, U, users, n_users, n_users, sign, Uh, Qb);
-  hipLaunchKernelGGL(k_init_rows, dim3((n_users + 255) / 256), dim3(256), 0, s, cnt, theta, flags_out, n_users);
+  hipLaunchKernelGGL(k_init_rows, dim3((n_users + 255) / 256), dim3(256), 0, s, cnt, theta, flags_out, n_users, nullptr);
   ANIREC_HIP_CHECK(hipGetLastError());
   CandArgs ca;
   ca.Qb = (const uint4 *)Qb;
@@ -938,6 +949,7 @@ int anirec_predict_topk_mfma(const float *U, const float *A, int32_t n_anime, co
   ra.hs = hs;
   ra.hb = hb;
   ra.sign = sign;
+  ra.unnorm = nullptr;  // k_norm_f16 normalises the rows itself
   // a zero / non-finite slope makes every rating equal (or NaN): nothing to rank on the MFMA side
   if (!(hs != 0.f) || !(hs == hs) || !(hb == hb)) {
     hipLaunchKernelGGL(k_flag_all, dim3((n_users + 255) / 256), dim3(256), 0, s, flags_out, n_users, out_idx, out_p, k);

@@ -105,11 +105,19 @@ class DistTrainEngine:
         """Full user table (all-gathered and re-interleaved); collective call."""
         return self.gather_user_table()
 
-    def gather_user_table(self):
+    def optimizer_state(self, iterations=0):
+        """Collective: the full-table Adam slots (user rows re-interleaved from the ranks' shards)."""
+        st = self.eng.optimizer_state(iterations)
+        nl = self.n_local
+        st["user_embedding/m"] = self.gather_user_table(self.eng.M[:nl]).cpu().numpy()
+        st["user_embedding/v"] = self.gather_user_table(self.eng.V[:nl]).cpu().numpy()
+        return st
+
+    def gather_user_table(self, local=None):
         self.eng.synchronize()
         n_max = local_user_rows(self.n_users, 0, self.world)
         mine = torch.zeros(n_max, _lib.DIM, dtype=torch.float32, device=self.device)
-        mine[: self.n_local] = self.eng.U
+        mine[: self.n_local] = self.eng.U if local is None else local
         parts = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(parts, mine)
         full = torch.empty(self.n_users, _lib.DIM, dtype=torch.float32, device=self.device)

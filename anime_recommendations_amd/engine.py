@@ -111,6 +111,16 @@ class TrainEngine:
         self.V.zero_()
         torch.cuda.synchronize(self.device)
 
+    def optimizer_state(self, iterations=0):
+        """Keras-Adam slots of every trainable (the optimizer part of model.save, neural_network.py:220-221):
+        first/second moments of both tables and of (w, b, gamma, beta), and the step counter."""
+        rec = self.read_state()
+        nu = self.n_user_rows
+        return {"user_embedding/m": self.M[:nu].cpu().numpy(), "user_embedding/v": self.V[:nu].cpu().numpy(),
+                "anime_embedding/m": self.M[nu:].cpu().numpy(), "anime_embedding/v": self.V[nu:].cpu().numpy(),
+                "head/m": np.array(rec["adam_m"], np.float32), "head/v": np.array(rec["adam_v"], np.float32),
+                "iterations": np.array([int(iterations)], np.int64)}
+
     # ---- descriptor ----------------------------------------------------------------
     def _build_desc(self):
         d = _lib.TrainDesc()

@@ -67,7 +67,10 @@ def preprocess_columns(cols, num_reviews, drop_unwatched=False, drop_plan=False,
     n = int(u.numel())
     dev = u.device
     if n == 0:
-        return {k: cols[k][:0] for k in COLUMNS}
+        out = {k: cols[k][:0] for k in COLUMNS}
+        if drop_half_watched:
+            out["max_eps"], out["half_eps"] = a[:0], r[:0]
+        return out
     opts = _lib.IngestOpts(int(num_reviews), int(bool(drop_unwatched)), int(bool(drop_plan)),
                            int(bool(drop_half_watched)), _bound(u), _bound(a))
     ou, oa = torch.empty_like(u), torch.empty_like(a)
@@ -80,14 +83,23 @@ def preprocess_columns(cols, num_reviews, drop_unwatched=False, drop_plan=False,
                                             C.byref(opts), _lib.ptr(ou), _lib.ptr(oa), _lib.ptr(orr),
                                             _lib.ptr(os_), _lib.ptr(oe), _lib.ptr(n_out), _lib.ptr(err),
                                             _lib.ptr(ws), ws.numel(), _stream()), "anirec_ingest_preprocess")
+    half = None
+    if drop_half_watched:        # the reference's frame keeps max_eps / half_eps for this flag (preprocess.py:99-104)
+        half = (torch.empty_like(a), torch.empty_like(r))
+        _lib.check(lib.anirec_ingest_half_columns(_lib.ptr(oa), _lib.ptr(n_out), n, C.byref(opts), _lib.ptr(half[0]),
+                                                  _lib.ptr(half[1]), _lib.ptr(ws), ws.numel(), _stream()),
+                   "anirec_ingest_half_columns")
     m = int(n_out.item())
     if int(err.item()):
         raise ValueError("negative user_id / anime_id in the rating table")
     if m and bool(torch.isnan(orr[0])):
         # max == min: the reference's scale_ratings raises here too (preprocess.py:115, Python floats)
         raise ZeroDivisionError("float division by zero (all surviving ratings are equal)")
-    return {"user_id": ou[:m], "anime_id": oa[:m], "rating": orr[:m], "watching_status": os_[:m],
-            "watched_episodes": oe[:m]}
+    out = {"user_id": ou[:m], "anime_id": oa[:m], "rating": orr[:m], "watching_status": os_[:m],
+           "watched_episodes": oe[:m]}
+    if half is not None:
+        out["max_eps"], out["half_eps"] = half[0][:m], half[1][:m]
+    return out
 
 
 def encode_ids(ids):
@@ -146,9 +158,10 @@ def encode_frame(df, shuffle=True, random_state=42, min_ratings=None, device="cu
     if min_ratings:
         n_ratings = df["user_id"].value_counts(dropna=True)
         df = df[df["user_id"].isin(n_ratings[n_ratings >= int(min_ratings)].index)]
-    ids = {}
+    ids, dtypes = {}, {}
     for name in ("user_id", "anime_id"):
         col = df[name].to_numpy()
+        dtypes[name] = col.dtype
         if col.dtype.kind not in "iu" or (col.size and (col.max() >= 2 ** 31 or col.min() < 0)):
             raise ValueError("%s must hold non-negative integers below 2^31 (the GPU encoder's id tables are "
                              "direct-indexed); got dtype %s" % (name, col.dtype))
@@ -160,7 +173,8 @@ def encode_frame(df, shuffle=True, random_state=42, min_ratings=None, device="cu
     if shuffle:
         order = data.shuffle_order(len(df), random_state)
         u, a, r = u[order], a[order], r[order]
-    return data.RatingTable(u, a, r, user_ids.cpu().numpy().astype(col.dtype), anime_ids.cpu().numpy().astype(col.dtype))
+    return data.RatingTable(u, a, r, user_ids.cpu().numpy().astype(dtypes["user_id"]),
+                            anime_ids.cpu().numpy().astype(dtypes["anime_id"]))
 
 
 def load_user_stats(path, **kw):

@@ -97,7 +97,9 @@ def cosine_topk(What, queries, k, exclude_self=True, keep=None, workspace=None):
 def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=65536, fallback=True):
     """cosine_topk on the matrix cores (fp16 MFMA candidates + exact fp32 re-rank); rows the
     kernel could not prove complete are transparently re-run through the exact kernels.
-    Returns (idx, score, n_fallback)."""
+    ``What`` must hold unit-norm rows (``rownorm`` output, as at every reference call site): the MFMA error
+    window is proven for unit vectors; the kernel checks it and un-normalised input sends EVERY query to the
+    exact path (correct, slow).  Returns (idx, score, n_fallback)."""
     _need_gpu()
     lib = _lib.load()
     assert What.is_cuda and What.dtype == torch.float32 and What.shape[1] == DIM
@@ -108,6 +110,8 @@ def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=65536
     nq = int(q.numel())
     out_i = torch.empty(nq, k, dtype=torch.int32, device=dev)
     out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
+    if nq == 0:                     # an empty query shard (dist_infer on more ranks than queries)
+        return out_i, out_s, 0
     keep_t = None
     if keep is not None:
         keep_t = torch.as_tensor(keep, device=dev).to(torch.uint8).contiguous()

@@ -157,6 +157,8 @@ def fit(table: RatingTable, cfg: FitConfig, engine=None, log=print, device="cuda
     rec = engine.read_state()
     res = FitResult(history=hist, U=engine.U.cpu().numpy().copy(), A=engine.A.cpu().numpy().copy(),
                     head=head_of(rec), best_epoch=best_epoch, stopped_epoch=stopped)
+    if hasattr(engine, "optimizer_state"):       # Adam m, v and the step count of the LAST epoch (model.save)
+        res.optimizer = engine.optimizer_state(iterations=t_global)
     if best_w is not None:
         best_w = (best_w[0].cpu().numpy(), best_w[1].cpu().numpy(), best_w[2])
         res.best_U, res.best_A, res.best_head = best_w

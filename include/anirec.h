@@ -208,6 +208,10 @@ int anirec_cosine_topk(const float *What, int32_t n, const int32_t *queries, int
 
 /* Same result as anirec_cosine_topk on the matrix cores: fp16 MFMA candidate scores for all
  * keys with a rigorous error window, exact fp32 fma-chain re-rank of the survivors.
+ * The error window is proven for UNIT-NORM rows (the output of anirec_rownorm, as every reference call
+ * site passes: similar_users.py:293 takes get_weights() output).  The conversion pass checks it: if any
+ * finite key or query row has | ||row||^2 - 1 | > 1e-3 every query is flagged (flags bit 2) and falls to the
+ * caller's exact re-run, so un-normalised input is slow, never silently incomplete.
  * flags[nq] (device) is non-zero for the rare query whose window could not be proven
  * complete (dense ties / more than 256 survivors); its output row is -1/NaN and the caller
  * re-runs it through anirec_cosine_topk.  k <= ANIREC_MAX_TOPK - 1. */
@@ -299,6 +303,14 @@ int anirec_ingest_preprocess(const int32_t *user_id, const int32_t *anime_id, co
                              const anirec_ingest_opts *opts, int32_t *out_user_id, int32_t *out_anime_id,
                              double *out_rating, int32_t *out_status, int32_t *out_episodes, int64_t *n_out,
                              int32_t *err_flag, void *workspace, size_t workspace_bytes, void *stream);
+
+/* With opts->drop_half_watched the reference's frame keeps two extra columns (preprocess.py:99-100,104):
+ * max_eps = the anime's largest watched_episodes over the rows that survived drop_useless, and
+ * half_eps = max_eps == 1 ? 1 : max_eps * .5.  Call right after anirec_ingest_preprocess with the SAME
+ * n, opts and workspace (the per-anime maxima are still in it); rows [0, *n_out) are written. */
+int anirec_ingest_half_columns(const int32_t *out_anime_id, const int64_t *n_out, int64_t n,
+                               const anirec_ingest_opts *opts, int32_t *out_max_eps, double *out_half_eps,
+                               const void *workspace, size_t workspace_bytes, void *stream);
 
 /* out_index[i] = position of id[i] in the order of first appearance (pandas Series.unique());
  * out_uniques[j] = the j-th distinct id; *n_unique (device) = number of distinct ids. */

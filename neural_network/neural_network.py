@@ -38,8 +38,18 @@ def go(args):
     if args.TPU_INIT:
         logger.info("TPU_INIT requested: ignored, training runs on MI355X (use torchrun for >1 GPU)")
     logger.info("Loading data artifact %s", args.input_data)
+    # one process per GPU under torchrun (RANK/WORLD_SIZE set): pick this rank's card before anything
+    # allocates on it, so the id tables of get_df land on cuda:LOCAL_RANK and not on cuda:0
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", rank)) if world > 1 else 0
+    import torch
+    if torch.cuda.is_available():
+        local %= torch.cuda.device_count()
+        torch.cuda.set_device(local)
     # get_df (neural_network.py:25-63 of the reference): the id encoding runs on the GPU (ingest.py)
-    table = ingest.load_user_stats(artifacts.use_artifact(args.input_data, args.main_df_type))
+    table = ingest.load_user_stats(artifacts.use_artifact(args.input_data, args.main_df_type),
+                                   device="cuda:%d" % local)
     logger.info("Final df shape is (%d, 3); %d users, %d anime", len(table), table.n_users, table.n_anime)
     cfg = trainer.FitConfig(
         epochs=int(args.epochs), batch_size=int(args.batch_size), test_size=int(args.test_size),
@@ -48,20 +58,26 @@ def go(args):
         rampup_epochs=int(args.rampup_epochs), sustain_epochs=int(args.sustain_epochs),
         exp_decay=float(args.exp_decay), monitor=args.checkpoint_metric, mode=args.mode,
         verbose=int(args.verbose), seed=int(os.environ.get("ANIREC_SEED", "0")))
-    # one process per GPU under torchrun (RANK/WORLD_SIZE set): ratings sharded by user, RCCL
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    engine, rank = None, 0
+    # >1 rank: ratings sharded by user over RCCL.  The reference's TPU branch (neural_network.py:173-178)
+    # computes batch_size * replicas and max_lr * replicas but never uses them: model.fit gets
+    # args.batch_size (:213) and lrfn reads args.max_lr (:113), so the GLOBAL batch and the schedule are
+    # unchanged by the replica count.  That actual behaviour is the default here (each rank takes
+    # batch_size // world of every global batch: same steps per epoch, same History, same early stop as
+    # one GPU); ANIREC_WEAK_SCALING=1 selects the branch's apparent intent instead (per-rank batch_size,
+    # max_lr * world).
+    engine = None
     if world > 1:
-        import torch
         import torch.distributed as dist
         from anime_recommendations_amd.dist import DistTrainEngine
-        rank = int(os.environ["RANK"])
-        local = int(os.environ.get("LOCAL_RANK", rank))
-        torch.cuda.set_device(local)
         if not dist.is_initialized():
             dist.init_process_group(os.environ.get("ANIREC_DIST_BACKEND", "nccl"))
         n_train = len(table) - cfg.test_size
-        engine = DistTrainEngine(table.n_users, table.n_anime, min(cfg.batch_size, max(1, n_train // world)),
+        if os.environ.get("ANIREC_WEAK_SCALING") == "1":
+            per_rank = cfg.batch_size
+            cfg.max_lr = cfg.max_lr * world
+        else:
+            per_rank = max(1, cfg.batch_size // world)
+        engine = DistTrainEngine(table.n_users, table.n_anime, min(per_rank, max(1, n_train // world)),
                                  l2=cfg.l2_reg_factor, device="cuda:%d" % local)
         if rank != 0:
             cfg.verbose = 0
@@ -80,7 +96,7 @@ def go(args):
     mpath = stem(args.model_name)
     if args.save_model:
         weights_io.save_model(mpath, res.U, res.A, res.head, table.user_ids, table.anime_ids,
-                              args.ID_emb_name, args.anime_emb_name,
+                              args.ID_emb_name, args.anime_emb_name, optimizer=res.optimizer,
                               extra={"best_epoch": res.best_epoch, "stopped_epoch": res.stopped_epoch})
     hist = trainer.history_frame(res.history)
     with open("history.json", "w") as f:

@@ -28,8 +28,10 @@ def drop_useless(df, num_reviews, drop_unwatched=False, drop_plan=False):
 def drop_half_watched(df):
     mx = df.groupby("anime_id")["watched_episodes"].max()          # :63-64
     half = pd.Series(np.where(mx == 1, mx, mx * .5), index=mx.index)  # :79-84
-    bound = df["anime_id"].map(half)
-    return df[df["watched_episodes"] >= bound]                      # :104
+    df = df.copy()
+    df["max_eps"] = df["anime_id"].map(mx).to_numpy()               # :99  (the two columns stay in the frame)
+    df["half_eps"] = df["anime_id"].map(half).to_numpy()            # :100
+    return df[df["watched_episodes"] >= df["half_eps"]]             # :104
 
 
 def scale_ratings(df):

@@ -28,6 +28,9 @@ def go(args):
     # same column order and dtypes as the reference's frame (ids / status / episodes int64, rating float64)
     out = pd.DataFrame({k: (cols[k].cpu().numpy() if k == "rating" else cols[k].cpu().numpy().astype("int64"))
                         for k in ingest.COLUMNS})
+    if args.drop_half_watched:       # the reference's frame keeps these two columns (preprocess.py:99-100,104)
+        out["max_eps"] = cols["max_eps"].cpu().numpy().astype("int64")
+        out["half_eps"] = cols["half_eps"].cpu().numpy()
     logger.info("Final df shape is %s", out.shape)
     logger.info("Final df columns are %s", out.columns)
     filename = args.preprocessed_stats
