@@ -17,9 +17,10 @@ DIM = 128
 MAX_BATCH = 16384
 CHUNK = 32
 ADAM_BLOCKS = 8192
+HOT_BLOCKS_MAX = 4352      # kHotBlocksMax of csrc/anirec_train.hip (workspace layout mirror, tests only)
 MAX_TOPK = 128
 MAX_SEG = 16
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class AnirecError(RuntimeError):
@@ -51,12 +52,13 @@ assert STATE_DTYPE.itemsize == 168, STATE_DTYPE.itemsize
 class TrainDesc(C.Structure):
     _fields_ = [
         ("n_user_rows", C.c_int32), ("n_anime_rows", C.c_int32), ("max_batch", C.c_int32),
-        ("arena_steps", C.c_int32), ("anime_dense", C.c_int32), ("n_seg", C.c_int32),
-        ("my_seg", C.c_int32), ("pad0", C.c_int32), ("l2", C.c_float), ("pad1", C.c_float),
+        ("arena_steps", C.c_int32), ("dense_mode", C.c_int32), ("n_seg", C.c_int32),
+        ("my_seg", C.c_int32), ("dense_rows", C.c_int32), ("l2", C.c_float), ("adam_row_lo", C.c_int32),
+        ("adam_row_hi", C.c_int32), ("pad1", C.c_int32),
         ("W", C.c_void_p), ("M", C.c_void_p), ("V", C.c_void_p), ("rowmap", C.c_void_p),
         ("state", C.c_void_p), ("user_idx", C.c_void_p), ("anime_idx", C.c_void_p),
         ("rating", C.c_void_p), ("sched", C.c_void_p), ("n_steps", C.c_int32), ("pad2", C.c_int32),
-        ("packets", C.c_void_p), ("anime_grad", C.c_void_p), ("workspace", C.c_void_p),
+        ("packets", C.c_void_p), ("dense_grad", C.c_void_p), ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_size_t),
     ]
 
@@ -88,6 +90,10 @@ PROTOTYPES = {
     "anirec_train_bwd": (C.c_int, [_DP, _vp]),
     "anirec_train_adam": (C.c_int, [_DP, _vp]),
     "anirec_train_adam_part": (C.c_int, [_DP, _i32, _vp]),
+    "anirec_dist_stepper_create": (C.c_int, [_DP, C.POINTER(_vp)]),
+    "anirec_dist_stepper_destroy": (C.c_int, [_vp]),
+    "anirec_dist_step_mid": (C.c_int, [_vp, _vp]),
+    "anirec_dist_step_back": (C.c_int, [_vp, _vp]),
     "anirec_trainer_create": (C.c_int, [_DP, C.POINTER(_vp)]),
     "anirec_trainer_destroy": (C.c_int, [_vp]),
     "anirec_trainer_run": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),

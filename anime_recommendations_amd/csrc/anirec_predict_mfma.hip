@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "anirec_dev.hpp"
 
@@ -27,11 +28,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // l2_normalize (tf epsilon 1e-12) a gathered row, scale by 2^8 and split into fp16 hi / lo planes.
 // out layout: [rows][2][128] halves (hi plane then lo plane of the row: 512 B per row)
-__global__ __launch_bounds__(256) void k_norm_split(const float *W, const int32_t *rows, int n,
+// rows n .. n_pad-1 of the output are zero rows (tile padding of the anime table)
+__global__ __launch_bounds__(256) void k_norm_split(const float *W, const int32_t *rows, int n, int n_pad,
                                                     _Float16 *out) {
   const int l = threadIdx.x & 31;
   const int nhw = gridDim.x * 8;
-  for (int r = blockIdx.x * 8 + (threadIdx.x >> 5); r < n; r += nhw) {
+  for (int r = blockIdx.x * 8 + (threadIdx.x >> 5); r < n_pad; r += nhw) {
+    if (r >= n) {
+      uint2 *o = reinterpret_cast<uint2 *>(out + (size_t)r * 2 * kDim);
+      o[l] = make_uint2(0u, 0u);
+      o[kRowVec + l] = make_uint2(0u, 0u);
+      continue;
+    }
     const int src = rows ? rows[r] : r;
     const float4 x = reinterpret_cast<const float4 *>(W)[(size_t)src * kRowVec + l];
     float ss = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
@@ -144,6 +152,149 @@ __global__ __launch_bounds__(256, 2) void k_predict_mfma(PredArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_predict_mfma2: the same grid with the operand roles swapped and a pipelined epilogue.
+//   * v_mfma_f32_16x16x32_f16 with the ANIME rows as the A (row) operand and the users as the B (column)
+//     operand: a lane's four accumulator registers of a 16x16 block are four CONSECUTIVE anime of ONE user,
+//     so the epilogue is one 16-byte store per block (8 per tile and wave, 16 users x 64 B each) instead of
+//     32 dword stores; the stores are non-temporal buffer stores (the 7.2 GB grid is written once) whose
+//     range check drops rows past n_users and columns past n_anime without branches.
+//   * the anime tile goes global -> LDS by LDS-DMA (no staging registers), two tiles resident;
+//   * sigmoid + store of tile t-1 are interleaved with the 96 MFMAs of tile t (second accumulator set):
+//     the store tail never runs on its own.
+// Requires n_anime % 4 == 0 (16-byte aligned row quads); other shapes take k_predict_mfma.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct Acc2 {
+  f32x4 c[4][2];  // [anime block of 16][user block of 16]
+};
+
+__global__ __launch_bounds__(256, 2) void k_predict_mfma2(PredArgs a) {
+  __shared__ __attribute__((aligned(16))) uint4 Ks[2][kPN * 32];  // 2 x 32 KB: hi+lo planes of 64 anime rows
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c16 = lane & 15, gq = lane >> 4;
+  const int u0 = blockIdx.x * kPM;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+
+  // B operand: user (16 ub + c16) of the wave's 32, k = 32 kk + 8 gq + j
+  f16x8 uh[2][4], ul[2][4];
+#pragma unroll
+  for (int ub = 0; ub < 2; ++ub) {
+    const int urow = u0 + 32 * w + 16 * ub + c16;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      u32x4 vh = {0u, 0u, 0u, 0u}, vl = {0u, 0u, 0u, 0u};
+      if (urow < a.n_users) {
+        vh = *reinterpret_cast<const u32x4 *>(&a.Ub[(size_t)urow * 32 + 4 * kk + gq]);
+        vl = *reinterpret_cast<const u32x4 *>(&a.Ub[(size_t)urow * 32 + 16 + 4 * kk + gq]);
+      }
+      uh[ub][kk] = __builtin_bit_cast(f16x8, vh);
+      ul[ub][kk] = __builtin_bit_cast(f16x8, vl);
+    }
+  }
+  // anime tile t: 64 rows x 512 B, LDS image [row][32 chunks] with slot = plane + ((chunk & 15) ^ (row & 15));
+  // LDS-DMA writes lane-linear, so the swizzle is applied to the per-lane SOURCE chunk.  A wave moves 8 pieces
+  // of 1 KiB (2 rows each) per tile.  Ab is padded with zero rows to whole tiles: no bounds test.
+  uint32_t doff[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = 16 * w + 2 * i + (lane >> 5);
+    const int sl = lane & 31;
+    doff[i] = (uint32_t)(r * 512 + ((sl & 16) + ((sl & 15) ^ (r & 15))) * 16);
+  }
+  const uint32_t ks_base =
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&Ks[0][0] + (uint32_t)wu * 8192u;
+  auto dma_tile = [&](int t, int buf) {
+    const char *base = reinterpret_cast<const char *>(a.Ab) + (size_t)t * (kPN * 512);
+    const uint32_t l0 = ks_base + (uint32_t)buf * (kPN * 512);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                   :
+                   : "v"(doff[i]), "s"(base), "s"(l0 + 1024u * i)
+                   : "memory", "m0");
+  };
+  // A operand read addresses: anime row 16 ab + c16 has (row & 15) == c16
+  const f16x8 *ka[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+    ka[kk] = reinterpret_cast<const f16x8 *>(&Ks[0][c16 * 32 + ((4 * kk + gq) ^ c16)]);
+
+  // output: per-workgroup buffer descriptor over rows [u0, u0 + valid rows): rows past n_users and the byte
+  // offset 0xFFFFFFF0 used for columns past n_anime fail the range check and are dropped by the hardware
+  const int rows_valid = min(kPM, a.n_users - u0);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      a.out + (size_t)u0 * a.n_anime, 0, (int)((size_t)rows_valid * a.n_anime * 4), 0x00020000);
+  uint32_t vrow[2];
+#pragma unroll
+  for (int ub = 0; ub < 2; ++ub) vrow[ub] = (uint32_t)((32 * w + 16 * ub + c16) * a.n_anime + 4 * gq) * 4u;
+  // sigmoid(c * hs + hb) = 1 / (1 + 2^(c * nhs + nhb))
+  const float nhs = -a.hs * 1.44269504088896341f, nhb = -a.hb * 1.44269504088896341f;
+
+  const int ntiles = (a.n_anime + kPN - 1) / kPN;
+  dma_tile(0, 0);
+  if (ntiles > 1) dma_tile(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // kEpi: interleave the epilogue of `cur` (tile tc) with the MFMAs of `nxt` (tile in buffer `buf`)
+  auto step = [&](Acc2 &nxt, const Acc2 &cur, int buf, int tc, bool epi) {
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const f16x8 ah = ka[kk][(buf * kPN + 16 * ab) * 32];
+        const f16x8 al = ka[kk][(buf * kPN + 16 * ab) * 32 + 16];
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub) {
+          f32x4 c = nxt.c[ab][ub];
+          if (kk == 0) c = (f32x4){0.f, 0.f, 0.f, 0.f};
+          // small terms first: lo*hi + hi*lo, then hi*hi
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, uh[ub][kk], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ul[ub][kk], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, uh[ub][kk], c, 0, 0, 0);
+          nxt.c[ab][ub] = c;
+        }
+        if (epi && (kk & 1)) {  // 8 epilogue blocks per tile, one after every 12 MFMAs
+          const int eb = 2 * ab + (kk >> 1);  // 0..7 -> (anime block eb >> 1, user block eb & 1)
+          const int eab = eb >> 1, eub = eb & 1;
+          const f32x4 v = cur.c[eab][eub];
+          f32x4 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            o[i] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(v[i], nhs, nhb)));
+          const int col = tc * kPN + 16 * eab + 4 * gq;
+          const uint32_t voff = col < a.n_anime ? vrow[eub] + (uint32_t)(tc * kPN + 16 * eab) * 4u : 0xFFFFFFF0u;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsrc, voff, 0, 2 /* nt */);
+        }
+      }
+    }
+  };
+  Acc2 accA, accB;
+  step(accA, accA, 0, 0, false);
+  __syncthreads();  // everyone is done with buffer 0
+  int t = 1;
+  for (; t + 1 < ntiles; t += 2) {
+    if (t + 1 < ntiles) dma_tile(t + 1, 0);
+    step(accB, accA, 1, t - 1, true);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the tile landed; the 8 younger stores stay in flight
+    __syncthreads();
+    if (t + 2 < ntiles) dma_tile(t + 2, 1);
+    step(accA, accB, 0, t, true);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __syncthreads();
+  }
+  if (t < ntiles) {  // one tile left (in buffer 1), results of tile t-1 in accA
+    step(accB, accA, 1, t - 1, true);
+    step(accA, accB, 0, t, true);  // MFMAs on stale buffer 0 are thrown away; only the epilogue of tile t matters
+  } else {           // results of the last tile in accA
+    step(accB, accA, 0, t - 1, true);
+  }
+}
+
 static inline void head_affine_mfma(const anirec_head *hd, float *hs, float *hb) {
   const float inv = (1.0f / sqrtf(hd->mov_var + kBnEps)) * hd->gamma;
   *hs = hd->w * inv / (kSplitScale * kSplitScale);
@@ -159,7 +310,7 @@ extern "C" {
 // workspace: split-fp16 copies of A (n_anime * 512 B) and of the query users (n_users * 512 B)
 size_t anirec_predict_mfma_workspace_bytes(int32_t n_anime, int32_t n_users) {
   if (n_anime < 1 || n_users < 1) return 0;
-  return ((size_t)n_anime + (size_t)n_users) * 512 + 512;
+  return (((size_t)n_anime + kPN - 1) / kPN * kPN + (size_t)n_users) * 512 + 512;
 }
 
 int anirec_predict_grid_mfma(const float *U, const float *A, int32_t n_anime, const int32_t *users,
@@ -170,13 +321,14 @@ int anirec_predict_grid_mfma(const float *U, const float *A, int32_t n_anime, co
   if (n_users == 0) return ANIREC_OK;
   if (workspace_bytes < anirec_predict_mfma_workspace_bytes(n_anime, n_users)) return ANIREC_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
+  const int n_pad = (n_anime + kPN - 1) / kPN * kPN;  // whole tiles: the LDS-DMA of k_predict_mfma2 has no bounds test
   _Float16 *Ab = (_Float16 *)workspace;
-  _Float16 *Ub = Ab + (size_t)n_anime * 2 * kDim;
+  _Float16 *Ub = Ab + (size_t)n_pad * 2 * kDim;
   int b1 = (n_anime + 7) / 8, b2 = (n_users + 7) / 8;
   if (b1 > 8192) b1 = 8192;
   if (b2 > 8192) b2 = 8192;
-  hipLaunchKernelGGL(k_norm_split, dim3(b1), dim3(256), 0, s, A, nullptr, n_anime, Ab);
-  hipLaunchKernelGGL(k_norm_split, dim3(b2), dim3(256), 0, s, U, users, n_users, Ub);
+  hipLaunchKernelGGL(k_norm_split, dim3(b1), dim3(256), 0, s, A, nullptr, n_anime, n_pad, Ab);
+  hipLaunchKernelGGL(k_norm_split, dim3(b2), dim3(256), 0, s, U, users, n_users, n_users, Ub);
   ANIREC_HIP_CHECK(hipGetLastError());
   PredArgs pa;
   pa.Ub = (const uint4 *)Ub;
@@ -185,7 +337,13 @@ int anirec_predict_grid_mfma(const float *U, const float *A, int32_t n_anime, co
   pa.n_anime = n_anime;
   head_affine_mfma(head, &pa.hs, &pa.hb);
   pa.out = out;
-  hipLaunchKernelGGL(k_predict_mfma, dim3((n_users + kPM - 1) / kPM), dim3(256), 0, s, pa);
+  // 16-byte row quads need n_anime % 4 == 0 and 32-bit byte offsets inside a workgroup's 128 rows
+  const char *ver = getenv("ANIREC_PREDICT_KERNEL");  // "1": force the dword-store kernel (A/B on one box)
+  const bool v2 = (n_anime % 4 == 0) && ((size_t)n_anime * kPM * 4 < ((size_t)1 << 31)) && !(ver && ver[0] == '1');
+  if (v2)
+    hipLaunchKernelGGL(k_predict_mfma2, dim3((n_users + kPM - 1) / kPM), dim3(256), 0, s, pa);
+  else
+    hipLaunchKernelGGL(k_predict_mfma, dim3((n_users + kPM - 1) / kPM), dim3(256), 0, s, pa);
   return (int)hipGetLastError();
 }
 

@@ -13,12 +13,21 @@
 //   bwd   half-wave per chunk: weighted sum of the OTHER table's rows, accumulated in
 //         registers in a fixed order, one coalesced 512-B store per chunk (no float atomics)
 //   adam  half-wave per table row, dense: g = chunk sums - s*W + 2*l2*W, Keras-2.12 Adam,
-//         emits sum(W_new^2) partials for the L2 loss term; workgroup 0 finishes the step
-//         (Adam on the 4 head scalars, moving stats, History metrics, step cursor).  HBM-bound: 24 B/element
+//         emits sum(W_new^2) partials for the L2 loss term.  HBM-bound: 24 B/element
 //         (+512 B per touched row) instead of 28 because the dense gradient never exists.
+//         On one GPU the update of step t is cut in two launches so that the small kernels of step t+1
+//         leave the critical path:
+//           hot(t)   the rows batch t+1 touches (the first-chunk records of its prepared slot) + the step
+//                    finish (Adam on the 4 head scalars, moving stats, History metrics, step cursor);
+//           rest(t)  every other row — the long HBM stream — beside which fwd/head/bwd(t+1) run on a
+//                    second branch of the captured graph (they only read rows hot(t) has finished).
+//         Per-step scratch (chunk partials, row map, head partials, step constants, L2 partials) is
+//         double-buffered by step parity so bwd(t+1) never overwrites what rest(t) still reads.
 //
-// All kernels read the step index from device memory (anirec_state::step_fwd/step_bwd)
-// so one captured hipGraph replays for every step.
+// All kernels read the step index from device memory so one captured hipGraph replays for every step:
+// fwd/head(t) from anirec_state::step_fwd (bumped by the finish of step t-1), bwd/hot(t) from the word
+// head(t) publishes (TrainWs::sel), rest(t) from anirec_state::step_bwd (set by the finish of step t,
+// which hot(t) contains).  Each word has exactly one writer that runs strictly before its readers.
 #include <hip/hip_runtime.h>
 
 #include <new>
@@ -35,18 +44,24 @@ struct StepPub {
   int slot, n_total, n_head_blocks, step;
   float alpha, mu, var, rs;
   float w, b, gamma, beta;
-  float reg_u, reg_a, l2, pad0;  // sum(U_local^2), sum(A^2) of the weights this step reads
+  float l2, pad0, pad1, pad2;
 };
+
+constexpr int kHotBlocksMax = 4352;  // >= ceil(2 * chunk_capacity(ANIREC_MAX_BATCH) / 8), multiple of 256
 
 struct TrainWs {
   int cap, capC, arena_steps;
   float *su, *sa;               // [cap] row square sums from fwd
   float *dy;                    // [cap] d loss / d y from head
-  float *hpart;                 // [ANIREC_MAX_SEG * ceil(cap/256)][8] head partial sums
-  StepPub *pub;                 // step constants published by head workgroup 0
-  float *regpart;               // [2][ANIREC_ADAM_BLOCKS]: user-row / anime-row sum(W^2) partials
-  float *P;                     // [2*capC][128] chunk partial rows
-  float *S;                     // [2*capC]      chunk self-coefficient sums
+  // everything below this line is double-buffered by step parity (index p = step & 1)
+  float *hpart;                 // [2][ANIREC_MAX_SEG * ceil(cap/256)][8] head partial sums
+  size_t hpart_stride;          // floats per parity
+  StepPub *pub;                 // [2] step constants published by head workgroup 0
+  int32_t *sel;                 // step index of the last head launch (read by bwd / densify / hot / full adam)
+  float *regpart;               // [2][2][ANIREC_ADAM_BLOCKS]: user-row / anime-row sum(W^2) partials of rest / full adam
+  float *reghot;                // [2][2][kHotBlocksMax]: the same of the hot launch
+  float *P;                     // [2][2*capC][128] chunk partial rows
+  float *S;                     // [2][2*capC]      chunk self-coefficient sums
   // arena slot s: nchunks[2] (4 ints), sidx[2][cap], oth[2][cap], chunks[2][capC] (int4)
   char *arena;
   size_t slot_bytes;
@@ -77,11 +92,14 @@ __host__ inline TrainWs carve(void *base, int cap, int arena_steps) {
   w.su = (float *)take(sizeof(float) * cap);
   w.sa = (float *)take(sizeof(float) * cap);
   w.dy = (float *)take(sizeof(float) * cap);
-  w.hpart = (float *)take(sizeof(float) * 8 * ANIREC_MAX_SEG * (size_t)((cap + 255) / 256));
-  w.pub = (StepPub *)take(sizeof(StepPub));
-  w.regpart = (float *)take(sizeof(float) * 2 * ANIREC_ADAM_BLOCKS);
-  w.P = (float *)take(sizeof(float) * 2 * (size_t)w.capC * kDim);
-  w.S = (float *)take(sizeof(float) * 2 * (size_t)w.capC);
+  w.hpart_stride = 8 * ANIREC_MAX_SEG * (size_t)((cap + 255) / 256);
+  w.hpart = (float *)take(sizeof(float) * 2 * w.hpart_stride);
+  w.pub = (StepPub *)take(sizeof(StepPub) * 2);
+  w.sel = (int32_t *)take(sizeof(int32_t) * 4);
+  w.regpart = (float *)take(sizeof(float) * 2 * 2 * ANIREC_ADAM_BLOCKS);
+  w.reghot = (float *)take(sizeof(float) * 2 * 2 * kHotBlocksMax);
+  w.P = (float *)take(sizeof(float) * 2 * 2 * (size_t)w.capC * kDim);
+  w.S = (float *)take(sizeof(float) * 2 * 2 * (size_t)w.capC);
   w.slot_bytes = align_up(16) + 2 * align_up(sizeof(int32_t) * 2 * (size_t)cap) +
                  align_up(sizeof(int4) * 2 * (size_t)w.capC);
   w.arena = take(w.slot_bytes * (size_t)arena_steps);
@@ -415,9 +433,10 @@ struct HeadArgs {
   size_t packet_floats;
   int n_seg, my_seg, cap, arena_steps;
   float *dy;             // [cap] d loss / d y of this rank's ratings
-  float *hpart;          // [n_seg*blocks_per_seg][8]
-  StepPub *pub;
-  const float *regpart;
+  float *hpart;          // [2][n_seg*blocks_per_seg][8]
+  size_t hpart_stride;
+  StepPub *pub;          // [2]
+  int32_t *sel;
   float l2;
 };
 
@@ -480,13 +499,6 @@ __global__ __launch_bounds__(kHeadThreads) void k_head(HeadArgs a) {
   const float *mypk = a.packets + a.packet_floats * seg;
   const float my_c = i < a.cap ? mypk[i] : 0.f;
   const float my_t = i < a.cap ? mypk[pcap + i] : 0.f;
-  constexpr int kRegVec = 2 * ANIREC_ADAM_BLOCKS / (4 * kHeadThreads);  // user half then anime half
-  float4 rp[kRegVec];
-  if (blockIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < kRegVec; ++k)
-      rp[k] = reinterpret_cast<const float4 *>(a.regpart)[tid + k * kHeadThreads];
-  }
   const int step = st->step_fwd;
   const float w = st->w, b = st->b, gamma = st->gamma, beta = st->beta;
   int cnts[ANIREC_MAX_SEG];
@@ -562,15 +574,10 @@ __global__ __launch_bounds__(kHeadThreads) void k_head(HeadArgs a) {
     if (seg == a.my_seg) a.dy[i] = dy;
   }
   block_sum<kHeadCols>(r, scratch);
-  if (tid < kHeadCols) a.hpart[(size_t)blockIdx.x * kHeadCols + tid] = r[tid];
+  const int par = step & 1;
+  if (tid < kHeadCols) a.hpart[par * a.hpart_stride + (size_t)blockIdx.x * kHeadCols + tid] = r[tid];
 
   if (blockIdx.x == 0) {
-    // L2 term: sum(W^2) of the weights this step reads (partials left by adam / init_reg)
-    float q[2] = {0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < kRegVec; ++k)
-      q[k >= kRegVec / 2 ? 1 : 0] += (rp[k].x + rp[k].y) + (rp[k].z + rp[k].w);
-    block_sum<2>(q, scratch);
     if (tid == 0) {
       StepPub p;
       p.slot = step % a.arena_steps;
@@ -585,11 +592,10 @@ __global__ __launch_bounds__(kHeadThreads) void k_head(HeadArgs a) {
       p.b = b;
       p.gamma = gamma;
       p.beta = beta;
-      p.reg_u = q[0];
-      p.reg_a = q[1];
       p.l2 = a.l2;
-      p.pad0 = 0.f;
-      *a.pub = p;
+      p.pad0 = p.pad1 = p.pad2 = 0.f;
+      a.pub[par] = p;
+      a.sel[0] = step;
     }
   }
 }
@@ -599,8 +605,11 @@ __global__ __launch_bounds__(kHeadThreads) void k_head(HeadArgs a) {
 // ------------------------------------------------------------------------------------
 struct BwdArgs {
   const float *W;
-  const StepPub *pub;
+  const StepPub *pub;    // [2]
+  const int32_t *sel;
   const float *hpart;
+  size_t hpart_stride;
+  int rows;              // table rows: stride of the two row maps
   char *arena;
   size_t slot_bytes;
   int cap, capC;
@@ -612,7 +621,9 @@ struct BwdArgs {
 
 __global__ __launch_bounds__(256) void k_bwd(BwdArgs a) {
   __shared__ float scratch[2 * 16];
-  const StepPub pub = *a.pub;
+  const int par = a.sel[0] & 1;
+  const StepPub pub = a.pub[par];
+  const float *hpart = a.hpart + par * a.hpart_stride;
   const int l = threadIdx.x & 31;
   const int hw = blockIdx.x * 8 + (threadIdx.x >> 5);
   const int T = hw >= a.capC ? 1 : 0;
@@ -650,8 +661,8 @@ __global__ __launch_bounds__(256) void k_bwd(BwdArgs a) {
   // mean(d zhat), mean(d zhat * zhat) from the head partials (fixed order)
   float m[2] = {0.f, 0.f};
   for (int k = threadIdx.x; k < pub.n_head_blocks; k += 256) {
-    m[0] += a.hpart[(size_t)k * kHeadCols + 0];
-    m[1] += a.hpart[(size_t)k * kHeadCols + 1];
+    m[0] += hpart[(size_t)k * kHeadCols + 0];
+    m[1] += hpart[(size_t)k * kHeadCols + 1];
   }
   block_sum<2>(m, scratch);
   if (!active) return;
@@ -706,64 +717,83 @@ __global__ __launch_bounds__(256) void k_bwd(BwdArgs a) {
     }
   }
   const float ssum = halfwave_sum(sf);
-  const int gc = T * a.capC + c;
-  reinterpret_cast<float4 *>(a.P)[(size_t)gc * kRowVec + l] = acc;
+  const int gc = T * a.capC + c;  // chunk index inside this parity's P / S
+  const size_t pc = (size_t)par * 2 * a.capC + gc;
+  reinterpret_cast<float4 *>(a.P)[pc * kRowVec + l] = acc;
   if (l == 0) {
-    a.S[gc] = ssum;
-    if (rec.w > 0) a.rowmap[rec.x] = ((gc << 10) | (rec.w - 1)) + 1;
+    a.S[pc] = ssum;
+    if (rec.w > 0) a.rowmap[(size_t)par * a.rows + rec.x] = ((gc << 10) | (rec.w - 1)) + 1;
   }
 }
 
-// densify the anime gradient for the RCCL all-reduce (multi-GPU): anime_grad[row] =
-// sum of the row's chunk partials, trailing n_anime floats = self-coefficient sums.
+// densify part of the gradient for an RCCL collective (multi-GPU): dense[r] = sum of the chunk partials of table
+// row dense_lo + r, then dense_rows self-coefficient sums; rows past the table (padding to a multiple of the
+// world size for reduce-scatter) are written as zeros.  dense_lo = n_user_rows: the replicated anime table of the
+// user-sharded mode; dense_lo = 0: both tables (the literal replicated-table data parallelism).
 struct DensifyArgs {
-  int n_user_rows, n_anime_rows;
+  int dense_lo, n_rows, dense_rows, rows, capC;
+  const int32_t *sel;
   int32_t *rowmap;
   const float *P, *S;
-  float *anime_grad;
+  float *dense;
 };
 
 __global__ __launch_bounds__(256) void k_densify(DensifyArgs a) {
   const int l = threadIdx.x & 31;
   const int nhw = gridDim.x * 8;
-  for (int r = blockIdx.x * 8 + (threadIdx.x >> 5); r < a.n_anime_rows; r += nhw) {
-    const int rm = a.rowmap[a.n_user_rows + r];
+  const int par = a.sel[0] & 1;
+  const float4 *P4 = reinterpret_cast<const float4 *>(a.P) + (size_t)par * 2 * a.capC * kRowVec;
+  const float *S = a.S + (size_t)par * 2 * a.capC;
+  int32_t *rowmap = a.rowmap + (size_t)par * a.rows;
+  for (int r = blockIdx.x * 8 + (threadIdx.x >> 5); r < a.dense_rows; r += nhw) {
+    const int gr = a.dense_lo + r;
+    const int rm = gr < a.n_rows ? rowmap[gr] : 0;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     float s = 0.f;
     if (rm) {
       const int first = (rm - 1) >> 10, nch = ((rm - 1) & 1023) + 1;
       for (int c = first; c < first + nch; ++c) {
-        const float4 p = reinterpret_cast<const float4 *>(a.P)[(size_t)c * kRowVec + l];
+        const float4 p = P4[(size_t)c * kRowVec + l];
         g.x += p.x;
         g.y += p.y;
         g.z += p.z;
         g.w += p.w;
-        s += a.S[c];
+        s += S[c];
       }
-      if (l == 0) a.rowmap[a.n_user_rows + r] = 0;
+      if (l == 0) rowmap[gr] = 0;
     }
-    reinterpret_cast<float4 *>(a.anime_grad)[(size_t)r * kRowVec + l] = g;
-    if (l == 0) a.anime_grad[(size_t)a.n_anime_rows * kDim + r] = s;
+    reinterpret_cast<float4 *>(a.dense)[(size_t)r * kRowVec + l] = g;
+    if (l == 0) a.dense[(size_t)a.dense_rows * kDim + r] = s;
   }
 }
 
 // ------------------------------------------------------------------------------------
-// adam: dense fused update of every table row; workgroup 0 finishes the step (scalar
-// Adam, moving statistics, History metrics, cursor)
+// adam: dense fused update of table rows; the finish of a step (scalar Adam, moving statistics,
+// History metrics, cursor) rides in workgroup 0 of the hot launch (one GPU) or of the last full
+// launch (multi-GPU)
 // ------------------------------------------------------------------------------------
 struct AdamArgs {
   float *W, *M, *V;
-  int n_rows, n_user_rows, n_anime_rows;
-  int row_lo;   // this launch covers rows [row_lo, n_rows)  (n_rows = exclusive upper bound)
-  int parts;    // bit0: write the user-row L2 partials, bit1: the anime-row ones, bit2: finish the step
-  int32_t *rowmap;
+  int n_rows;       // this launch covers rows [row_lo, n_rows)
+  int row_lo;
+  int n_user_rows;  // rows below it count into the user L2 partial, the others into the anime one
+  int rows;         // all table rows (stride of the two row maps)
+  int capC;
+  int parts;        // bit0: write the user-row L2 partials, bit1: the anime-row ones, bit2: finish the step
+  int step_src;     // 0: step = *sel (launches that run before the step's finish); 1: state->step_bwd (rest)
+  int dense_lo, dense_rows;  // dense != nullptr: rows >= dense_lo take their (already reduced) gradient from it
+  int rest_blocks, hot_blocks;  // grids whose L2 partials the finish adds up
+  int32_t *rowmap;  // [2][rows]
   const float *P, *S;
-  float *anime_grad;  // non-null: anime rows take their gradient from here (already reduced)
+  const float *dense;
   anirec_state *state;
-  const StepPub *pub;
+  const StepPub *pub;  // [2]
+  const int32_t *sel;
   const float *hpart;
+  size_t hpart_stride;
   float two_l2;
-  float *regpart;
+  float *regpart;  // [2][2][ANIREC_ADAM_BLOCKS]
+  float *reghot;   // [2][2][kHotBlocksMax]
 };
 
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -782,44 +812,52 @@ __device__ __forceinline__ void st_nt(float4 *p, const float4 &v) {
 struct RowLoad {
   float4 w, m, v, p0;  // p0: first chunk partial (zero if the row is untouched)
   float s0;
-  int rm;
+  int rm;              // > 0: chunk list; 0: untouched; < 0: already updated by the hot launch (skip)
 };
 
 // issue every load of one row up front: W, M, V and — the row map word having been
 // prefetched one iteration earlier — the first chunk partial of a touched row
-template <bool kUpdate, bool kNT>
-__device__ __forceinline__ void row_issue(const AdamArgs &a, int r, int l, int rm, RowLoad &x) {
+template <bool kNT>
+__device__ __forceinline__ void row_issue(const AdamArgs &a, int par, int r, int l, int rm, RowLoad &x) {
   const size_t e = (size_t)r * kRowVec + l;
-  const float4 *Wp = reinterpret_cast<const float4 *>(a.W) + e;
-  x.w = kNT ? ld_nt(Wp) : *Wp;
   x.rm = rm;
-  if (kUpdate) {
-    const float4 *Mp = reinterpret_cast<const float4 *>(a.M) + e;
-    const float4 *Vp = reinterpret_cast<const float4 *>(a.V) + e;
-    x.m = kNT ? ld_nt(Mp) : *Mp;
-    x.v = kNT ? ld_nt(Vp) : *Vp;
-    x.p0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    x.s0 = 0.f;
-    if (a.anime_grad != nullptr && r >= a.n_user_rows) {
-      const int ar = r - a.n_user_rows;
-      x.p0 = reinterpret_cast<const float4 *>(a.anime_grad)[(size_t)ar * kRowVec + l];
-      x.s0 = a.anime_grad[(size_t)a.n_anime_rows * kDim + ar];
-      x.rm = 0;
-    } else if (rm) {
-      const int first = (rm - 1) >> 10;
-      x.p0 = reinterpret_cast<const float4 *>(a.P)[(size_t)first * kRowVec + l];
-      x.s0 = a.S[first];
-    }
+  x.p0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  x.s0 = 0.f;
+  if (rm < 0) return;
+  const float4 *Wp = reinterpret_cast<const float4 *>(a.W) + e;
+  const float4 *Mp = reinterpret_cast<const float4 *>(a.M) + e;
+  const float4 *Vp = reinterpret_cast<const float4 *>(a.V) + e;
+  x.w = kNT ? ld_nt(Wp) : *Wp;
+  x.m = kNT ? ld_nt(Mp) : *Mp;
+  x.v = kNT ? ld_nt(Vp) : *Vp;
+  if (a.dense != nullptr && r >= a.dense_lo) {
+    const int dr = r - a.dense_lo;
+    x.p0 = reinterpret_cast<const float4 *>(a.dense)[(size_t)dr * kRowVec + l];
+    x.s0 = a.dense[(size_t)a.dense_rows * kDim + dr];
+    x.rm = 0;
+  } else if (rm) {
+    const size_t first = (size_t)par * 2 * a.capC + ((rm - 1) >> 10);
+    x.p0 = reinterpret_cast<const float4 *>(a.P)[first * kRowVec + l];
+    x.s0 = a.S[first];
   }
 }
 
+// returns sum(W_new^2) of this lane's four elements (0 for a skipped row); `mark` is what the row map word of a
+// touched row becomes: 0 (consumed) or -1 (hot launch: "already updated", cleared by the rest launch)
 template <bool kNT>
-__device__ __forceinline__ void row_finish(const AdamArgs &a, int r, int l, float alpha, RowLoad &x) {
+__device__ __forceinline__ float row_finish(const AdamArgs &a, int par, int r, int l, float alpha, RowLoad &x,
+                                            int mark) {
+  int32_t *rmw = a.rowmap + (size_t)par * a.rows + r;
+  if (x.rm < 0) {
+    if (l == 0) *rmw = 0;
+    return 0.f;
+  }
   const size_t e = (size_t)r * kRowVec + l;
   float4 g = x.p0;
   float s = x.s0;
   if (x.rm) {
-    const float4 *P4 = reinterpret_cast<const float4 *>(a.P);
+    const float4 *P4 = reinterpret_cast<const float4 *>(a.P) + (size_t)par * 2 * a.capC * kRowVec;
+    const float *S = a.S + (size_t)par * 2 * a.capC;
     const int first = (x.rm - 1) >> 10, nch = ((x.rm - 1) & 1023) + 1;
     for (int c = first + 1; c < first + nch; ++c) {  // rows with > ANIREC_CHUNK contributions
       const float4 p = P4[(size_t)c * kRowVec + l];
@@ -827,10 +865,10 @@ __device__ __forceinline__ void row_finish(const AdamArgs &a, int r, int l, floa
       g.y += p.y;
       g.z += p.z;
       g.w += p.w;
-      s += a.S[c];
+      s += S[c];
     }
-    if (l == 0) a.rowmap[r] = 0;
   }
+  if ((x.rm || mark) && l == 0) *rmw = mark;
   float4 w = x.w, m = x.m, v = x.v;
   g.x = grad_total(g.x, s, w.x, a.two_l2);
   g.y = grad_total(g.y, s, w.y, a.two_l2);
@@ -849,120 +887,211 @@ __device__ __forceinline__ void row_finish(const AdamArgs &a, int r, int l, floa
     reinterpret_cast<float4 *>(a.M)[e] = m;
     reinterpret_cast<float4 *>(a.V)[e] = v;
   }
-  x.w = w;
+  return w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
 }
 
-template <bool kUpdate, bool kNT>
-__global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
-  __shared__ float scratch[kHeadCols * 16];
-  const int l = threadIdx.x & 31;
-  const int nhw = gridDim.x * 8;
-  float alpha = 0.f;
-  if (kUpdate) alpha = a.pub->alpha;
-  float sq = 0.f, sqa = 0.f;  // sum(W_new^2) over user rows / anime rows of this thread
-  int r = a.row_lo + blockIdx.x * 8 + (threadIdx.x >> 5);
-  // two rows in flight per half-wave; the row-map words of the NEXT pair are fetched one
-  // iteration ahead so a touched row's chunk partial is requested together with W/M/V
-  int rm0 = 0, rm1 = 0;
-  if (kUpdate) {
-    if (r < a.n_rows) rm0 = a.rowmap[r];
-    if (r + nhw < a.n_rows) rm1 = a.rowmap[r + nhw];
-  }
-  for (; r + nhw < a.n_rows; r += 2 * nhw) {
-    const int r1 = r + nhw;
-    RowLoad x0, x1;
-    row_issue<kUpdate, kNT>(a, r, l, rm0, x0);
-    row_issue<kUpdate, kNT>(a, r1, l, rm1, x1);
-    if (kUpdate) {
-      const int rn0 = r + 2 * nhw, rn1 = r + 3 * nhw;
-      rm0 = rn0 < a.n_rows ? a.rowmap[rn0] : 0;
-      rm1 = rn1 < a.n_rows ? a.rowmap[rn1] : 0;
-      row_finish<kNT>(a, r, l, alpha, x0);
-      row_finish<kNT>(a, r1, l, alpha, x1);
-    }
-    const float q0 = x0.w.x * x0.w.x + x0.w.y * x0.w.y + x0.w.z * x0.w.z + x0.w.w * x0.w.w;
-    const float q1 = x1.w.x * x1.w.x + x1.w.y * x1.w.y + x1.w.z * x1.w.z + x1.w.w * x1.w.w;
-    if (r < a.n_user_rows) sq += q0; else sqa += q0;
-    if (r1 < a.n_user_rows) sq += q1; else sqa += q1;
-  }
-  if (r < a.n_rows) {
-    RowLoad x0;
-    row_issue<kUpdate, kNT>(a, r, l, rm0, x0);
-    if (kUpdate) row_finish<kNT>(a, r, l, alpha, x0);
-    const float q0 = x0.w.x * x0.w.x + x0.w.y * x0.w.y + x0.w.z * x0.w.z + x0.w.w * x0.w.w;
-    if (r < a.n_user_rows) sq += q0; else sqa += q0;
-  }
-  // block partial of sum(W_new^2), fixed order
+// block partial of sum(W_new^2): user rows / anime rows, fixed order
+__device__ __forceinline__ void block_sq_partials(float sq, float sqa, float *scratch, float *out_u, float *out_a) {
   sq = wave_sum(sq);
   sqa = wave_sum(sqa);
+  __syncthreads();
   if ((threadIdx.x & 63) == 0) {
     scratch[threadIdx.x >> 6] = sq;
     scratch[4 + (threadIdx.x >> 6)] = sqa;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (a.parts & 1) a.regpart[blockIdx.x] = scratch[0] + scratch[1] + scratch[2] + scratch[3];
-    if (a.parts & 2)
-      a.regpart[ANIREC_ADAM_BLOCKS + blockIdx.x] = scratch[4] + scratch[5] + scratch[6] + scratch[7];
+    if (out_u) *out_u = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    if (out_a) *out_a = scratch[4] + scratch[5] + scratch[6] + scratch[7];
   }
   __syncthreads();
+}
 
-  if (kUpdate && blockIdx.x == 0 && (a.parts & 4)) {
-    // finish the step: reduce the head partials, Adam on (w, b, gamma, beta), moving stats
-    const StepPub pub = *a.pub;
-    float h[kHeadCols];
+// the end of step t (one workgroup of 256 threads): reduce the head partials, Adam on (w, b, gamma, beta), moving
+// statistics, History sums, cursors.  The L2 term of the loss is sum(W^2) of the weights step t READ: the partials
+// the launches of step t-1 (or init_reg) left in the other parity.
+__device__ __forceinline__ void finish_step(const AdamArgs &a, int par, float *scratch) {
+  const StepPub pub = a.pub[par];
+  const float *hpart = a.hpart + par * a.hpart_stride;
+  float h[kHeadCols];
 #pragma unroll
-    for (int k = 0; k < kHeadCols; ++k) h[k] = 0.f;
-    for (int blk = threadIdx.x; blk < pub.n_head_blocks; blk += 256) {
+  for (int k = 0; k < kHeadCols; ++k) h[k] = 0.f;
+  for (int blk = threadIdx.x; blk < pub.n_head_blocks; blk += 256) {
 #pragma unroll
-      for (int k = 0; k < kHeadCols; ++k) h[k] += a.hpart[(size_t)blk * kHeadCols + k];
+    for (int k = 0; k < kHeadCols; ++k) h[k] += hpart[(size_t)blk * kHeadCols + k];
+  }
+  const int pp = par ^ 1;
+  float q[2] = {0.f, 0.f};
+  const float *ru = a.regpart + (size_t)(pp * 2 + 0) * ANIREC_ADAM_BLOCKS, *ra = ru + ANIREC_ADAM_BLOCKS;
+  for (int i = threadIdx.x; i < a.rest_blocks; i += 256) {
+    q[0] += ru[i];
+    q[1] += ra[i];
+  }
+  const float *hu = a.reghot + (size_t)(pp * 2 + 0) * kHotBlocksMax, *ha = hu + kHotBlocksMax;
+  for (int i = threadIdx.x; i < a.hot_blocks; i += 256) {
+    q[0] += hu[i];
+    q[1] += ha[i];
+  }
+  block_sum<kHeadCols>(h, scratch);
+  block_sum<2>(q, scratch);
+  if (threadIdx.x == 0) {
+    anirec_state *st = a.state;
+    const double n = (double)pub.n_total;
+    const double S1 = h[0], S2 = h[1], L = h[2], SE = h[3];
+    const double Sdc = h[4], Sc = h[5], Szc = h[6], Sz = h[7];
+    const double g = pub.gamma, rs = pub.rs;
+    const double m1 = g * S1 / n, m2 = g * S2 / n;
+    // sum dz*c and sum dz with dz = (gamma*dy - m1 - zh*m2)*rs, expanded over the batch sums
+    const float dW = (float)(rs * (g * Sdc - m1 * Sc - m2 * Szc));
+    const float dB = (float)(rs * (g * S1 - n * m1 - m2 * Sz));
+    float p4[4] = {pub.w, pub.b, pub.gamma, pub.beta};
+    const float g4[4] = {dW, dB, (float)S2, (float)S1};  // d w, d b, d gamma, d beta
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float mm = st->adam_m[k], vv = st->adam_v[k];
+      adam_elem(p4[k], mm, vv, g4[k], pub.alpha);
+      st->adam_m[k] = mm;
+      st->adam_v[k] = vv;
     }
-    block_sum<kHeadCols>(h, scratch);
-    if (threadIdx.x == 0) {
-      anirec_state *st = a.state;
-      const double n = (double)pub.n_total;
-      const double S1 = h[0], S2 = h[1], L = h[2], SE = h[3];
-      const double Sdc = h[4], Sc = h[5], Szc = h[6], Sz = h[7];
-      const double g = pub.gamma, rs = pub.rs;
-      const double m1 = g * S1 / n, m2 = g * S2 / n;
-      // sum dz*c and sum dz with dz = (gamma*dy - m1 - zh*m2)*rs, expanded over the batch sums
-      const float dW = (float)(rs * (g * Sdc - m1 * Sc - m2 * Szc));
-      const float dB = (float)(rs * (g * S1 - n * m1 - m2 * Sz));
-      float p4[4] = {pub.w, pub.b, pub.gamma, pub.beta};
-      const float g4[4] = {dW, dB, (float)S2, (float)S1};  // d w, d b, d gamma, d beta
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float mm = st->adam_m[k], vv = st->adam_v[k];
-        adam_elem(p4[k], mm, vv, g4[k], pub.alpha);
-        st->adam_m[k] = mm;
-        st->adam_v[k] = vv;
+    st->w = p4[0];
+    st->b = p4[1];
+    st->gamma = p4[2];
+    st->beta = p4[3];
+    const float mmean = st->mov_mean, mvar = st->mov_var;
+    st->mov_mean = mmean - (mmean - pub.mu) * kBnDecay;
+    st->mov_var = mvar - (mvar - pub.var) * kBnDecay;
+    const float reg_u = q[0], reg_a = q[1];
+    const float reg = reg_u + reg_a;
+    st->reg_sumsq = reg;
+    st->reg_user_sumsq = reg_u;
+    st->reg_anime_sumsq = reg_a;
+    st->bn_mu = pub.mu;
+    st->bn_var = pub.var;
+    const float loss = (float)(L / n) + pub.l2 * reg;
+    st->last_loss = loss;
+    st->last_mse = (float)(SE / n);
+    st->loss_wsum += (double)loss * n;
+    st->bce_wsum += L;
+    st->reg_user_wsum += (double)reg_u * n;
+    st->reg_anime_wsum += (double)reg_a * n;
+    st->se_sum += SE;
+    st->n_seen += n;
+    st->step_bwd = pub.step;
+    st->step_fwd = pub.step + 1;
+  }
+}
+
+// kRest: the second launch of a one-GPU step — rows the hot launch already updated carry -1 in the row map and
+// are skipped (word cleared); no finish.  !kRest: every row of [row_lo, n_rows) (multi-GPU parts, with finish
+// when parts & 4).
+template <bool kNT, bool kRest>
+__global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
+  __shared__ float scratch[kHeadCols * 16];
+  const int l = threadIdx.x & 31;
+  const int nhw = gridDim.x * 8;
+  const int step = a.step_src ? a.state->step_bwd : a.sel[0];
+  const int par = step & 1;
+  const float alpha = a.pub[par].alpha;
+  const int32_t *rowmap = a.rowmap + (size_t)par * a.rows;
+  float sq = 0.f, sqa = 0.f;  // sum(W_new^2) over user rows / anime rows of this thread
+  int r = a.row_lo + blockIdx.x * 8 + (threadIdx.x >> 5);
+  // two rows in flight per half-wave; the row-map words of the NEXT pair are fetched one
+  // iteration ahead so a touched row's chunk partial is requested together with W/M/V
+  int rm0 = 0, rm1 = 0;
+  if (r < a.n_rows) rm0 = rowmap[r];
+  if (r + nhw < a.n_rows) rm1 = rowmap[r + nhw];
+  for (; r + nhw < a.n_rows; r += 2 * nhw) {
+    const int r1 = r + nhw;
+    RowLoad x0, x1;
+    row_issue<kNT>(a, par, r, l, rm0, x0);
+    row_issue<kNT>(a, par, r1, l, rm1, x1);
+    const int rn0 = r + 2 * nhw, rn1 = r + 3 * nhw;
+    rm0 = rn0 < a.n_rows ? rowmap[rn0] : 0;
+    rm1 = rn1 < a.n_rows ? rowmap[rn1] : 0;
+    const float q0 = row_finish<kNT>(a, par, r, l, alpha, x0, 0);
+    const float q1 = row_finish<kNT>(a, par, r1, l, alpha, x1, 0);
+    if (r < a.n_user_rows) sq += q0; else sqa += q0;
+    if (r1 < a.n_user_rows) sq += q1; else sqa += q1;
+  }
+  if (r < a.n_rows) {
+    RowLoad x0;
+    row_issue<kNT>(a, par, r, l, rm0, x0);
+    const float q0 = row_finish<kNT>(a, par, r, l, alpha, x0, 0);
+    if (r < a.n_user_rows) sq += q0; else sqa += q0;
+  }
+  float *rp = a.regpart + (size_t)(par * 2) * ANIREC_ADAM_BLOCKS;
+  block_sq_partials(sq, sqa, scratch, (a.parts & 1) ? rp + blockIdx.x : nullptr,
+                    (a.parts & 2) ? rp + ANIREC_ADAM_BLOCKS + blockIdx.x : nullptr);
+  if (!kRest && blockIdx.x == 0 && (a.parts & 4)) finish_step(a, par, scratch);
+}
+
+// hot(t): the rows batch t+1 touches — one half-wave per chunk record of its prepared slot, the first chunk of a
+// row standing for the row — get their step-t update first (plain loads/stores: fwd/bwd(t+1) read them right
+// away), are marked -1 in the row map for the rest launch, and workgroup 0 finishes the step.  Any set of rows is
+// a valid hot set (every row is updated exactly once per step by hot or rest), so a slot that was prepared for
+// another step only costs speed, never correctness.
+struct HotArgs {
+  AdamArgs a;
+  char *arena;
+  size_t slot_bytes;
+  int cap, arena_steps, n_steps_total;
+};
+
+__global__ __launch_bounds__(256) void k_adam_hot(HotArgs h) {
+  __shared__ float scratch[kHeadCols * 16];
+  const AdamArgs &a = h.a;
+  const int l = threadIdx.x & 31;
+  const int step = a.sel[0];
+  const int par = step & 1;
+  const float alpha = a.pub[par].alpha;
+  const int hw = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int T = hw >= a.capC ? 1 : 0;
+  const int c = hw - T * a.capC;
+  float sq = 0.f, sqa = 0.f;
+  if (step + 1 < h.n_steps_total && T < 2) {
+    Slot sl = slot_of(h.arena, h.slot_bytes, h.cap, a.capC, (step + 1) % h.arena_steps);
+    if (c < min(sl.nchunks[T], a.capC)) {
+      const int4 rec = sl.chunks[T * a.capC + c];
+      const int r = rec.x;
+      if (rec.w > 0 && r >= 0 && r < a.rows) {
+        RowLoad x;
+        row_issue<false>(a, par, r, l, a.rowmap[(size_t)par * a.rows + r], x);
+        const float q = row_finish<false>(a, par, r, l, alpha, x, -1);
+        if (r < a.n_user_rows) sq = q; else sqa = q;
       }
-      st->w = p4[0];
-      st->b = p4[1];
-      st->gamma = p4[2];
-      st->beta = p4[3];
-      const float mmean = st->mov_mean, mvar = st->mov_var;
-      st->mov_mean = mmean - (mmean - pub.mu) * kBnDecay;
-      st->mov_var = mvar - (mvar - pub.var) * kBnDecay;
-      const float reg = pub.reg_u + pub.reg_a;
-      st->reg_sumsq = reg;
-      st->reg_user_sumsq = pub.reg_u;
-      st->reg_anime_sumsq = pub.reg_a;
-      st->bn_mu = pub.mu;
-      st->bn_var = pub.var;
-      const float loss = (float)(L / n) + pub.l2 * reg;
-      st->last_loss = loss;
-      st->last_mse = (float)(SE / n);
-      st->loss_wsum += (double)loss * n;
-      st->bce_wsum += L;
-      st->reg_user_wsum += (double)pub.reg_u * n;
-      st->reg_anime_wsum += (double)pub.reg_a * n;
-      st->se_sum += SE;
-      st->n_seen += n;
-      st->step_bwd = pub.step;
-      st->step_fwd = pub.step + 1;
     }
   }
+  float *rh = a.reghot + (size_t)(par * 2) * kHotBlocksMax;
+  block_sq_partials(sq, sqa, scratch, rh + blockIdx.x, rh + kHotBlocksMax + blockIdx.x);
+  if (blockIdx.x == 0) finish_step(a, par, scratch);
+}
+
+// sum(W^2) partials of the CURRENT weights into both parities (after (re)loading weights, before validation):
+// the next step's finish reads them whatever its parity
+__global__ __launch_bounds__(256) void k_reg_init(const float *W, int row_lo, int n_rows, int n_user_rows,
+                                                  float *regpart, float *reghot) {
+  __shared__ float scratch[16];
+  const int l = threadIdx.x & 31;
+  const int nhw = gridDim.x * 8;
+  float sq = 0.f, sqa = 0.f;
+  for (int r = row_lo + blockIdx.x * 8 + (threadIdx.x >> 5); r < n_rows; r += nhw) {
+    const float4 w = reinterpret_cast<const float4 *>(W)[(size_t)r * kRowVec + l];
+    const float q = w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
+    if (r < n_user_rows) sq += q; else sqa += q;
+  }
+  float u = 0.f, an = 0.f;
+  __shared__ float res[2];
+  block_sq_partials(sq, sqa, scratch, &res[0], &res[1]);
+  u = res[0];
+  an = res[1];
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      regpart[(size_t)(p * 2 + 0) * ANIREC_ADAM_BLOCKS + blockIdx.x] = u;
+      regpart[(size_t)(p * 2 + 1) * ANIREC_ADAM_BLOCKS + blockIdx.x] = an;
+    }
+  }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < 4 * kHotBlocksMax; i += gridDim.x * 256) reghot[i] = 0.f;
 }
 
 // flat Adam with an explicit gradient (unit-testable bit-exact stage)
@@ -1059,14 +1188,22 @@ __global__ __launch_bounds__(256) void k_gather_ratings(const int32_t *ui, const
 // ------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------
+static inline int table_rows(const anirec_train_desc *d) { return d->n_user_rows + d->n_anime_rows; }
+// first table row whose gradient travels through the dense buffer
+static inline int dense_lo_of(const anirec_train_desc *d) { return d->dense_mode == 2 ? 0 : d->n_user_rows; }
+
 static int check_desc(const anirec_train_desc *d) {
   if (!d || !d->W || !d->M || !d->V || !d->rowmap || !d->state || !d->workspace || !d->packets)
     return ANIREC_EINVAL;
   if (d->max_batch < 1 || d->max_batch > ANIREC_MAX_BATCH) return ANIREC_EINVAL;
-  if (d->n_user_rows < 1 || d->n_anime_rows < 1 || d->arena_steps < 1) return ANIREC_EINVAL;
+  if (d->n_user_rows < 1 || d->n_anime_rows < 1 || d->arena_steps < 2) return ANIREC_EINVAL;
   if (d->n_seg < 1 || d->n_seg > ANIREC_MAX_SEG || d->my_seg < 0 || d->my_seg >= d->n_seg)
     return ANIREC_EINVAL;
-  if (d->anime_dense && !d->anime_grad) return ANIREC_EINVAL;
+  if (d->dense_mode < 0 || d->dense_mode > 2) return ANIREC_EINVAL;
+  if (d->dense_mode) {
+    if (!d->dense_grad || d->dense_rows < table_rows(d) - dense_lo_of(d)) return ANIREC_EINVAL;
+    if (d->adam_row_lo < 0 || d->adam_row_hi < d->adam_row_lo || d->adam_row_hi > table_rows(d)) return ANIREC_EINVAL;
+  }
   if (d->workspace_bytes < anirec_train_workspace_bytes(d->max_batch, d->arena_steps))
     return ANIREC_EWORKSPACE;
   return ANIREC_OK;
@@ -1111,19 +1248,43 @@ static int launch_head(const anirec_train_desc *d, const TrainWs &w, hipStream_t
   a.arena_steps = d->arena_steps;
   a.dy = w.dy;
   a.hpart = w.hpart;
+  a.hpart_stride = w.hpart_stride;
   a.pub = w.pub;
-  a.regpart = w.regpart;
+  a.sel = w.sel;
   a.l2 = d->l2;
   const int bps = (d->max_batch + kHeadThreads - 1) / kHeadThreads;
   hipLaunchKernelGGL(k_head, dim3(bps * d->n_seg), dim3(kHeadThreads), 0, s, a);
   return (int)hipGetLastError();
 }
 
-static int launch_bwd(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
+static int launch_densify(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
+  DensifyArgs g;
+  g.dense_lo = dense_lo_of(d);
+  g.n_rows = table_rows(d);
+  g.dense_rows = d->dense_rows;
+  g.rows = table_rows(d);
+  g.capC = w.capC;
+  g.sel = w.sel;
+  g.rowmap = d->rowmap;
+  g.P = w.P;
+  g.S = w.S;
+  g.dense = d->dense_grad;
+  int blocks = (d->dense_rows + 7) / 8;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_densify, dim3(blocks), dim3(256), 0, s, g);
+  return (int)hipGetLastError();
+}
+
+// bwd only (the densify pass of the multi-GPU modes is a separate launch so that the caller can fork work
+// that needs the chunk partials but not the dense buffer)
+static int launch_bwd_only(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
   BwdArgs a;
   a.W = d->W;
   a.pub = w.pub;
+  a.sel = w.sel;
   a.hpart = w.hpart;
+  a.hpart_stride = w.hpart_stride;
+  a.rows = table_rows(d);
   a.arena = w.arena;
   a.slot_bytes = w.slot_bytes;
   a.cap = w.cap;
@@ -1136,61 +1297,96 @@ static int launch_bwd(const anirec_train_desc *d, const TrainWs &w, hipStream_t 
   a.S = w.S;
   a.rowmap = d->rowmap;
   hipLaunchKernelGGL(k_bwd, dim3((2 * w.capC + 7) / 8), dim3(256), 0, s, a);
-  int e = (int)hipGetLastError();
-  if (e) return e;
-  if (d->anime_dense) {
-    DensifyArgs g;
-    g.n_user_rows = d->n_user_rows;
-    g.n_anime_rows = d->n_anime_rows;
-    g.rowmap = d->rowmap;
-    g.P = w.P;
-    g.S = w.S;
-    g.anime_grad = d->anime_grad;
-    int blocks = (d->n_anime_rows + 7) / 8;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_densify, dim3(blocks), dim3(256), 0, s, g);
-    e = (int)hipGetLastError();
-  }
+  return (int)hipGetLastError();
+}
+
+static int launch_bwd(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
+  int e = launch_bwd_only(d, w, s);
+  if (!e && d->dense_mode) e = launch_densify(d, w, s);
   return e;
 }
+
+// Grid of every table-streaming launch of a descriptor (init, rest, full, parts): a function of the table
+// size only, so the same regpart entries are rewritten each step.  Two rows per half-wave at least, so the
+// two-rows-in-flight pipeline has something to overlap on small (cache-resident) tables.
+static inline int adam_grid(const anirec_train_desc *d) {
+  const long long rows = (long long)table_rows(d);
+  long long b = (rows + 15) / 16;
+  if (b < 64) b = 64;
+  if (b > ANIREC_ADAM_BLOCKS) b = ANIREC_ADAM_BLOCKS;
+  return (int)b;
+}
+static inline int hot_grid(const TrainWs &w) { return (2 * w.capC + 7) / 8; }
 
 static AdamArgs adam_args(const anirec_train_desc *d, const TrainWs &w) {
   AdamArgs a;
   a.W = d->W;
   a.M = d->M;
   a.V = d->V;
-  a.n_rows = d->n_user_rows + d->n_anime_rows;
+  a.n_rows = table_rows(d);
   a.row_lo = 0;
-  a.parts = 7;
   a.n_user_rows = d->n_user_rows;
-  a.n_anime_rows = d->n_anime_rows;
+  a.rows = table_rows(d);
+  a.capC = w.capC;
+  a.parts = 7;
+  a.step_src = 0;
+  a.dense_lo = dense_lo_of(d);
+  a.dense_rows = d->dense_rows;
+  a.rest_blocks = adam_grid(d);
+  a.hot_blocks = d->dense_mode ? 0 : hot_grid(w);
   a.rowmap = d->rowmap;
   a.P = w.P;
   a.S = w.S;
-  a.anime_grad = d->anime_dense ? d->anime_grad : nullptr;
+  a.dense = d->dense_mode ? d->dense_grad : nullptr;
   a.state = d->state;
   a.pub = w.pub;
+  a.sel = w.sel;
   a.hpart = w.hpart;
+  a.hpart_stride = w.hpart_stride;
   a.two_l2 = 2.0f * d->l2;
   a.regpart = w.regpart;
+  a.reghot = w.reghot;
   return a;
 }
 
-// Grid of every k_adam launch of a descriptor (init, whole step, user part, anime part): a function of
-// the table size only, so the same regpart entries are rewritten each step.  Two rows per half-wave at
-// least, so the two-rows-in-flight pipeline has something to overlap on small (cache-resident) tables.
-static inline int adam_grid(const anirec_train_desc *d) {
-  const long long rows = (long long)d->n_user_rows + d->n_anime_rows;
-  long long b = (rows + 15) / 16;
-  if (b < 64) b = 64;
-  if (b > ANIREC_ADAM_BLOCKS) b = ANIREC_ADAM_BLOCKS;
-  return (int)b;
+// tables that overflow the 256-MiB Infinity Cache are streamed non-temporally; small ones
+// (the 7M-rating shape: 50 MB of W+M+V) stay cache-resident between steps
+static inline bool stream_nt(const anirec_train_desc *d) {
+  return (size_t)table_rows(d) * kDim * 4 * 3 > ((size_t)192 << 20);
 }
 
-// which: 0 = every row (one launch), 1 = user rows only (may run while the anime gradient is
-// still being all-reduced), 2 = anime rows only + finish the step
-static int launch_adam(const anirec_train_desc *d, const TrainWs &w, hipStream_t s, int which = 0) {
+// One GPU: hot(t) — the rows of batch t+1 + the step finish; rest(t) — every other row.
+static int launch_adam_hot(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
+  HotArgs h;
+  h.a = adam_args(d, w);
+  h.arena = w.arena;
+  h.slot_bytes = w.slot_bytes;
+  h.cap = w.cap;
+  h.arena_steps = w.arena_steps;
+  h.n_steps_total = d->n_steps;
+  hipLaunchKernelGGL(k_adam_hot, dim3(hot_grid(w)), dim3(256), 0, s, h);
+  return (int)hipGetLastError();
+}
+
+static int launch_adam_rest(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
   AdamArgs a = adam_args(d, w);
+  a.parts = 3;
+  a.step_src = 1;
+  if (stream_nt(d))
+    hipLaunchKernelGGL((k_adam<true, true>), dim3(adam_grid(d)), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_adam<false, true>), dim3(adam_grid(d)), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+// Multi-GPU (dense_mode != 0).  which: 0 = every row this rank updates + finish, 1 = the user rows only (may
+// run while the anime gradient is still in the all-reduce: user-sharded mode), 2 = the anime rows + finish
+static int launch_adam_full(const anirec_train_desc *d, const TrainWs &w, hipStream_t s, int which) {
+  AdamArgs a = adam_args(d, w);
+  if (d->dense_mode == 2 && (d->adam_row_lo | d->adam_row_hi)) {  // reduce-scatter shard (possibly empty)
+    a.row_lo = d->adam_row_lo;
+    a.n_rows = d->adam_row_hi;
+  }
   if (which == 1) {
     a.n_rows = d->n_user_rows;
     a.parts = 1;
@@ -1198,14 +1394,17 @@ static int launch_adam(const anirec_train_desc *d, const TrainWs &w, hipStream_t
     a.row_lo = d->n_user_rows;
     a.parts = 2 | 4;
   }
-  // tables that overflow the 256-MiB Infinity Cache are streamed non-temporally; small ones
-  // (the 7M-rating shape: 50 MB of W+M+V) stay cache-resident between steps
-  const size_t table_bytes = (size_t)a.n_rows * kDim * 4 * 3;
-  if (table_bytes > ((size_t)192 << 20))
-    hipLaunchKernelGGL((k_adam<true, true>), dim3(adam_grid(d)), dim3(256), 0, s, a);
-  else
+  if (stream_nt(d))
     hipLaunchKernelGGL((k_adam<true, false>), dim3(adam_grid(d)), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_adam<false, false>), dim3(adam_grid(d)), dim3(256), 0, s, a);
   return (int)hipGetLastError();
+}
+
+static int launch_adam(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
+  if (d->dense_mode) return launch_adam_full(d, w, s, 0);
+  int e = launch_adam_hot(d, w, s);
+  return e ? e : launch_adam_rest(d, w, s);
 }
 
 }  // namespace anirec
@@ -1218,7 +1417,7 @@ extern "C" {
 size_t anirec_packet_floats(int32_t max_batch) { return 2 * (size_t)packet_cap(max_batch) + 4; }
 
 size_t anirec_train_workspace_bytes(int32_t max_batch, int32_t arena_steps) {
-  if (max_batch < 1 || max_batch > ANIREC_MAX_BATCH || arena_steps < 1) return 0;
+  if (max_batch < 1 || max_batch > ANIREC_MAX_BATCH || arena_steps < 2) return 0;
   return carve(nullptr, max_batch, arena_steps).total;
 }
 
@@ -1226,11 +1425,18 @@ int anirec_train_init_reg(const anirec_train_desc *d, void *stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   TrainWs w = carve(d->workspace, d->max_batch, d->arena_steps);
-  AdamArgs a = adam_args(d, w);
   hipStream_t s = (hipStream_t)stream;
   // entries beyond the grid are never written again: they must be (and stay) zero
-  ANIREC_HIP_CHECK(hipMemsetAsync(w.regpart, 0, sizeof(float) * 2 * ANIREC_ADAM_BLOCKS, s));
-  hipLaunchKernelGGL((k_adam<false, false>), dim3(adam_grid(d)), dim3(256), 0, s, a);
+  ANIREC_HIP_CHECK(hipMemsetAsync(w.regpart, 0, sizeof(float) * 4 * ANIREC_ADAM_BLOCKS, s));
+  // a rank that only updates a row shard (replicated tables + reduce-scatter) only counts that shard, like its
+  // adam launches do: the caller sums the ranks' values
+  int lo = 0, hi = table_rows(d);
+  if (d->dense_mode == 2 && (d->adam_row_lo | d->adam_row_hi)) {
+    lo = d->adam_row_lo;
+    hi = d->adam_row_hi;
+  }
+  hipLaunchKernelGGL(k_reg_init, dim3(adam_grid(d)), dim3(256), 0, s, d->W, lo, hi, d->n_user_rows, w.regpart,
+                     w.reghot);
   ANIREC_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(k_sum_regpart, dim3(1), dim3(1024), 0, s, d->state, w.regpart);
   return (int)hipGetLastError();
@@ -1298,28 +1504,118 @@ int anirec_train_adam(const anirec_train_desc *d, void *stream) {
 int anirec_train_adam_part(const anirec_train_desc *d, int32_t which, void *stream) {
   int rc = check_desc(d);
   if (rc) return rc;
-  if (which != 1 && which != 2) return ANIREC_EINVAL;
-  return launch_adam(d, carve(d->workspace, d->max_batch, d->arena_steps), (hipStream_t)stream, which);
+  TrainWs w = carve(d->workspace, d->max_batch, d->arena_steps);
+  hipStream_t s = (hipStream_t)stream;
+  switch (which) {
+    case 1:  // multi-GPU, user-sharded: the user rows
+    case 2:  // ... the anime rows + finish
+      if (d->dense_mode != 1) return ANIREC_EINVAL;
+      return launch_adam_full(d, w, s, which);
+    case 3:  // one GPU: hot rows + finish
+    case 4:  // one GPU: the rest
+      if (d->dense_mode != 0) return ANIREC_EINVAL;
+      return which == 3 ? launch_adam_hot(d, w, s) : launch_adam_rest(d, w, s);
+    default:
+      return ANIREC_EINVAL;
+  }
 }
 
+// ---- multi-GPU step halves (one C call each; the caller issues the two collectives between them) ----------
+struct anirec_dist_stepper {
+  anirec_train_desc d;
+  TrainWs ws;
+  hipStream_t side;
+  hipEvent_t fork, join;
+};
+
+int anirec_dist_stepper_create(const anirec_train_desc *d, anirec_dist_stepper **out) {
+  if (!out) return ANIREC_EINVAL;
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!d->dense_mode) return ANIREC_EINVAL;
+  anirec_dist_stepper *h = new (std::nothrow) anirec_dist_stepper;
+  if (!h) return ANIREC_EINVAL;
+  h->d = *d;
+  h->ws = carve(d->workspace, d->max_batch, d->arena_steps);
+  h->side = nullptr;
+  h->fork = h->join = nullptr;
+  if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->join, hipEventDisableTiming) != hipSuccess) {
+    anirec_dist_stepper_destroy(h);
+    return ANIREC_ENODEVICE;
+  }
+  *out = h;
+  return ANIREC_OK;
+}
+
+int anirec_dist_stepper_destroy(anirec_dist_stepper *h) {
+  if (!h) return ANIREC_EINVAL;
+  if (h->fork) (void)hipEventDestroy(h->fork);
+  if (h->join) (void)hipEventDestroy(h->join);
+  if (h->side) (void)hipStreamDestroy(h->side);
+  delete h;
+  return ANIREC_OK;
+}
+
+// after the all-gather of the head packets: head, bwd, and the densify pass that feeds the gradient collective.
+// User-sharded mode: the dense Adam stream over this rank's user rows needs nothing from the collective, so it
+// is forked onto the stepper's side stream right behind bwd and runs beside densify + all-reduce.
+int anirec_dist_step_mid(anirec_dist_stepper *h, void *stream) {
+  if (!h) return ANIREC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  int e;
+  if ((e = launch_head(&h->d, h->ws, s))) return e;
+  if ((e = launch_bwd_only(&h->d, h->ws, s))) return e;
+  if (h->d.dense_mode == 1) {
+    ANIREC_HIP_CHECK(hipEventRecord(h->fork, s));
+    ANIREC_HIP_CHECK(hipStreamWaitEvent(h->side, h->fork, 0));
+    if ((e = launch_adam_full(&h->d, h->ws, h->side, 1))) return e;
+    ANIREC_HIP_CHECK(hipEventRecord(h->join, h->side));
+  }
+  return launch_densify(&h->d, h->ws, s);
+}
+
+// after the gradient collective: the rows that needed it + the step finish
+int anirec_dist_step_back(anirec_dist_stepper *h, void *stream) {
+  if (!h) return ANIREC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (h->d.dense_mode == 1) {
+    ANIREC_HIP_CHECK(hipStreamWaitEvent(s, h->join, 0));
+    return launch_adam_full(&h->d, h->ws, s, 2);
+  }
+  return launch_adam_full(&h->d, h->ws, s, 0);
+}
+
+// ---- one GPU: the whole loop ------------------------------------------------------------------------------
 struct anirec_trainer {
   anirec_train_desc d;
   TrainWs ws;
   hipGraphExec_t exec;
   int graph_steps;
+  hipStream_t side;         // second graph branch: fwd/head/bwd(t+1) beside rest(t)
+  hipEvent_t fork, join;
 };
 
 int anirec_trainer_create(const anirec_train_desc *d, anirec_trainer **out) {
   if (!out) return ANIREC_EINVAL;
   int rc = check_desc(d);
   if (rc) return rc;
-  if (d->n_seg != 1 || d->anime_dense) return ANIREC_EINVAL;  // multi-GPU drives the stages itself
+  if (d->n_seg != 1 || d->dense_mode) return ANIREC_EINVAL;  // multi-GPU drives the step halves itself
   anirec_trainer *t = new (std::nothrow) anirec_trainer;
   if (!t) return ANIREC_EINVAL;
   t->d = *d;
   t->ws = carve(d->workspace, d->max_batch, d->arena_steps);
   t->exec = nullptr;
   t->graph_steps = 0;
+  t->side = nullptr;
+  t->fork = t->join = nullptr;
+  if (hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&t->fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&t->join, hipEventDisableTiming) != hipSuccess) {
+    anirec_trainer_destroy(t);
+    return ANIREC_ENODEVICE;
+  }
   *out = t;
   return ANIREC_OK;
 }
@@ -1327,22 +1623,52 @@ int anirec_trainer_create(const anirec_train_desc *d, anirec_trainer **out) {
 int anirec_trainer_destroy(anirec_trainer *t) {
   if (!t) return ANIREC_EINVAL;
   if (t->exec) (void)hipGraphExecDestroy(t->exec);
+  if (t->fork) (void)hipEventDestroy(t->fork);
+  if (t->join) (void)hipEventDestroy(t->join);
+  if (t->side) (void)hipStreamDestroy(t->side);
   delete t;
   return ANIREC_OK;
 }
 
-static int one_step(anirec_trainer *t, hipStream_t s) {
+static int front_of_step(anirec_trainer *t, hipStream_t s) {
   int e;
   if ((e = launch_fwd(&t->d, t->ws, s))) return e;
   if ((e = launch_head(&t->d, t->ws, s))) return e;
-  if ((e = launch_bwd(&t->d, t->ws, s))) return e;
-  return launch_adam(&t->d, t->ws, s);
+  return launch_bwd_only(&t->d, t->ws, s);
+}
+
+static int one_step(anirec_trainer *t, hipStream_t s) {
+  int e;
+  if ((e = front_of_step(t, s))) return e;
+  if ((e = launch_adam_hot(&t->d, t->ws, s))) return e;
+  return launch_adam_rest(&t->d, t->ws, s);
+}
+
+// G steps as a two-branch chain: front(0) hot(0) { rest(0) || front(1) } hot(1) { rest(1) || front(2) } ...
+// front(t+1) only reads rows that hot(t) has updated and writes the other parity's scratch, so it runs beside
+// the long rest(t) stream; hot(t+1) needs both.
+static int overlapped_steps(anirec_trainer *t, int G, hipStream_t s) {
+  int e = front_of_step(t, s);
+  for (int i = 0; i < G && !e; ++i) {
+    if ((e = launch_adam_hot(&t->d, t->ws, s))) break;
+    const bool more = i + 1 < G;
+    if (more) {
+      ANIREC_HIP_CHECK(hipEventRecord(t->fork, s));
+      ANIREC_HIP_CHECK(hipStreamWaitEvent(t->side, t->fork, 0));
+      if ((e = front_of_step(t, t->side))) break;
+      ANIREC_HIP_CHECK(hipEventRecord(t->join, t->side));
+    }
+    if ((e = launch_adam_rest(&t->d, t->ws, s))) break;
+    if (more) ANIREC_HIP_CHECK(hipStreamWaitEvent(s, t->join, 0));
+  }
+  return e;
 }
 
 // Runs steps [first_step, first_step + n_steps); first_step must equal the device cursor
 // (state->step_fwd).  The batch prep (sort + chunk tables) is driven from here: with use_graph a
 // captured graph of G steps starts with the prep of the G steps AFTER it (relative to the device
-// cursor), so a replay needs no host work between blocks; the arena holds 2G steps.
+// cursor), so a replay needs no host work between blocks; the arena holds 2G steps.  hot(t) reads the
+// prepared slot of step t+1: every path below has it prepared before step t runs.
 int anirec_trainer_run(anirec_trainer *t, int32_t first_step, int32_t n_steps, int32_t use_graph,
                        void *stream) {
   if (!t || n_steps < 0 || first_step < 0 || first_step + n_steps > t->d.n_steps) return ANIREC_EINVAL;
@@ -1352,7 +1678,8 @@ int anirec_trainer_run(anirec_trainer *t, int32_t first_step, int32_t n_steps, i
   int G = t->d.arena_steps / 2;
   if (G > 32) G = 32;
   int done = 0;
-  if (use_graph && s != nullptr && G >= 4 && n_steps >= G) {
+  const bool graph = use_graph && s != nullptr && G >= 4 && n_steps >= G;
+  if (graph) {
     if (!t->exec || t->graph_steps != G) {
       if (t->exec) (void)hipGraphExecDestroy(t->exec);
       t->exec = nullptr;
@@ -1360,7 +1687,7 @@ int anirec_trainer_run(anirec_trainer *t, int32_t first_step, int32_t n_steps, i
       if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess)
         return ANIREC_ECAPTURE;
       int e = launch_prep(&t->d, t->ws, G, G, true, s);  // steps cursor+G .. cursor+2G
-      for (int i = 0; i < G && !e; ++i) e = one_step(t, s);
+      if (!e) e = overlapped_steps(t, G, s);
       hipError_t ce = hipStreamEndCapture(s, &g);
       if (e || ce != hipSuccess || !g) {
         if (g) (void)hipGraphDestroy(g);
@@ -1380,15 +1707,14 @@ int anirec_trainer_run(anirec_trainer *t, int32_t first_step, int32_t n_steps, i
       ANIREC_HIP_CHECK(hipGraphLaunch(t->exec, s));
       done += G;
     }
-    // the last replay already prepared steps [first_step+done, first_step+done+G): the tail is covered
-  } else {
-    // no graph: prepare arena-sized blocks from the host
+    // the last replay already prepared steps [first_step+done, first_step+done+G): the tail (< G steps, and
+    // the slot after its last step) is covered
   }
   while (done < n_steps) {
     int blk = n_steps - done;
-    if (!(use_graph && s != nullptr && G >= 4 && done > 0)) {  // tail after a replay is prepared already
-      if (blk > t->d.arena_steps) blk = t->d.arena_steps;
-      int e = launch_prep(&t->d, t->ws, first_step + done, blk, false, s);
+    if (!(graph && done > 0)) {  // no replay before: prepare from the host, one slot beyond the block
+      if (blk > t->d.arena_steps - 1) blk = t->d.arena_steps - 1;
+      int e = launch_prep(&t->d, t->ws, first_step + done, blk + 1, false, s);
       if (e) return e;
     }
     for (int i = 0; i < blk; ++i) {

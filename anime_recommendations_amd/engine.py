@@ -6,7 +6,7 @@ All arithmetic of the train step runs in libanirec's HIP kernels.
 HBM layout (one rank):
   W, M, V     [(n_user_rows + n_anime_rows), 128] fp32 each — embeddings and Adam moments,
               users first then anime, so one dense Adam launch covers both tables
-  rowmap      [rows] int32 — per-step "row -> chunk list" map written by bwd, cleared by adam
+  rowmap      [2][rows] int32 — per-step "row -> chunk list" map written by bwd, cleared by adam (one per step parity)
   state       anirec_state (136 B) — scalar head, BN moving stats, step cursors, metrics
   epoch data  user_idx/anime_idx int32 + rating fp32 in shuffled epoch order (12 B/rating)
   sched       anirec_step[n_steps] — start/count/alpha of every step of the epoch
@@ -29,7 +29,11 @@ def _dev_bytes(n, device):
 
 class TrainEngine:
     def __init__(self, n_user_rows, n_anime_rows, max_batch, l2=1e-4, arena_steps=64,
-                 device="cuda:0", n_seg=1, my_seg=0, anime_dense=False):
+                 device="cuda:0", n_seg=1, my_seg=0, dense_mode=0, row_pad=1, adam_rows=None):
+        """dense_mode: 0 one GPU; 1 user-sharded DP (anime gradient through ``dense_grad``); 2 replicated
+        tables (every gradient through ``dense_grad``).  row_pad: the tables and the dense buffer are
+        allocated with their row count rounded up to a multiple of it (equal reduce-scatter / all-gather
+        shards).  adam_rows: (lo, hi) row shard this rank's Adam updates in mode 2, None = all."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.AnirecError("no GPU: the anime_recommendations_amd hot path needs an MI355X")
@@ -40,12 +44,16 @@ class TrainEngine:
         self.rows = self.n_user_rows + self.n_anime_rows
         self.max_batch, self.arena_steps = int(max_batch), int(arena_steps)
         self.l2 = float(l2)
-        self.n_seg, self.my_seg, self.anime_dense = int(n_seg), int(my_seg), bool(anime_dense)
+        self.n_seg, self.my_seg, self.dense_mode = int(n_seg), int(my_seg), int(dense_mode)
         dev = self.device
-        self.W = torch.zeros(self.rows, DIM, dtype=torch.float32, device=dev)
-        self.M = torch.zeros_like(self.W)
-        self.V = torch.zeros_like(self.W)
-        self.rowmap = torch.zeros(self.rows, dtype=torch.int32, device=dev)
+        row_pad = max(1, int(row_pad))
+        self.rows_alloc = (self.rows + row_pad - 1) // row_pad * row_pad
+        self._Wfull = torch.zeros(self.rows_alloc, DIM, dtype=torch.float32, device=dev)
+        self.W = self._Wfull[: self.rows]
+        self.M = torch.zeros(self.rows, DIM, dtype=torch.float32, device=dev)
+        self.V = torch.zeros_like(self.M)
+        self.rowmap = torch.zeros(2 * self.rows, dtype=torch.int32, device=dev)
+        self.adam_rows = (0, 0) if adam_rows is None else (int(adam_rows[0]), int(adam_rows[1]))
         self.state_buf = _dev_bytes(_lib.STATE_DTYPE.itemsize, dev)
         self.packet_floats = int(self.lib.anirec_packet_floats(self.max_batch))
         self.packets = torch.zeros(self.n_seg * self.packet_floats, dtype=torch.float32, device=dev)
@@ -53,9 +61,12 @@ class TrainEngine:
         if ws == 0:
             raise _lib.AnirecError("anirec_train_workspace_bytes rejected the geometry")
         self.workspace = _dev_bytes(ws, dev)
-        self.anime_grad = (torch.zeros(self.n_anime_rows * DIM + self.n_anime_rows,
-                                       dtype=torch.float32, device=dev)
-                           if self.anime_dense else None)
+        # dense gradient buffer of the multi-GPU modes: [dense_rows][128] gradients, then [dense_rows] self sums
+        carried = {0: 0, 1: self.n_anime_rows, 2: self.rows}[self.dense_mode]
+        self.dense_rows = (carried + row_pad - 1) // row_pad * row_pad
+        self.dense_grad = (torch.zeros(self.dense_rows * (DIM + 1), dtype=torch.float32, device=dev)
+                           if self.dense_mode else None)
+        self._stepper = None
         self.stream = torch.cuda.Stream(device=dev)
         self.user_idx = self.anime_idx = self.rating = self.sched = None
         self.n_steps = 0
@@ -126,7 +137,9 @@ class TrainEngine:
         d = _lib.TrainDesc()
         d.n_user_rows, d.n_anime_rows = self.n_user_rows, self.n_anime_rows
         d.max_batch, d.arena_steps = self.max_batch, self.arena_steps
-        d.anime_dense, d.n_seg, d.my_seg = int(self.anime_dense), self.n_seg, self.my_seg
+        d.dense_mode, d.n_seg, d.my_seg = self.dense_mode, self.n_seg, self.my_seg
+        d.dense_rows = self.dense_rows
+        d.adam_row_lo, d.adam_row_hi = self.adam_rows
         d.l2 = self.l2
         d.W, d.M, d.V = _lib.ptr(self.W), _lib.ptr(self.M), _lib.ptr(self.V)
         d.rowmap, d.state = _lib.ptr(self.rowmap), _lib.ptr(self.state_buf)
@@ -134,12 +147,15 @@ class TrainEngine:
         d.rating, d.sched = _lib.ptr(self.rating), _lib.ptr(self.sched)
         d.n_steps = self.n_steps
         d.packets = _lib.ptr(self.packets)
-        d.anime_grad = _lib.ptr(self.anime_grad)
+        d.dense_grad = _lib.ptr(self.dense_grad)
         d.workspace, d.workspace_bytes = _lib.ptr(self.workspace), self.workspace.numel()
         self._desc = d
         if self._trainer is not None:
             _lib.check(self.lib.anirec_trainer_destroy(self._trainer), "anirec_trainer_destroy")
             self._trainer = None
+        if self._stepper is not None:
+            _lib.check(self.lib.anirec_dist_stepper_destroy(self._stepper), "anirec_dist_stepper_destroy")
+            self._stepper = None
         return d
 
     @property
@@ -174,6 +190,8 @@ class TrainEngine:
         rec["step_bwd"] = 0
         self.write_state(rec)
         self._build_desc()
+        # the L2 partial sums are double-buffered by step parity and the cursor restarts at 0: refresh both
+        self.init_reg()
 
     def reset_metrics(self):
         rec = self.read_state()
@@ -205,11 +223,37 @@ class TrainEngine:
     def adam_anime_finish(self):
         _lib.check(self.lib.anirec_train_adam_part(C.byref(self.desc), 2, self._sp()), "anirec_train_adam_part")
 
+    def adam_hot(self):
+        """One GPU: the rows the next batch touches + the step finish (k_adam_hot)."""
+        _lib.check(self.lib.anirec_train_adam_part(C.byref(self.desc), 3, self._sp()), "anirec_train_adam_part")
+
+    def adam_rest(self):
+        """One GPU: every other row (the long HBM stream)."""
+        _lib.check(self.lib.anirec_train_adam_part(C.byref(self.desc), 4, self._sp()), "anirec_train_adam_part")
+
+    # ---- multi-GPU step halves: one C call each, the collectives go between them ------------
+    def _get_stepper(self):
+        if self._stepper is None:
+            h = C.c_void_p()
+            _lib.check(self.lib.anirec_dist_stepper_create(C.byref(self.desc), C.byref(h)),
+                       "anirec_dist_stepper_create")
+            self._stepper = h
+        return self._stepper
+
+    def step_front(self):
+        self.fwd()
+
+    def step_mid(self):
+        _lib.check(self.lib.anirec_dist_step_mid(self._get_stepper(), self._sp()), "anirec_dist_step_mid")
+
+    def step_back(self):
+        _lib.check(self.lib.anirec_dist_step_back(self._get_stepper(), self._sp()), "anirec_dist_step_back")
+
     # ---- the hot loop ---------------------------------------------------------------
     def run(self, n_steps=None, use_graph=True, first_step=None):
         """Run n_steps optimiser steps from the current cursor (prep + fwd/head/bwd/adam)."""
-        if self.n_seg != 1 or self.anime_dense:
-            raise _lib.AnirecError("TrainEngine.run is the single-GPU loop; use DistTrainer")
+        if self.n_seg != 1 or self.dense_mode:
+            raise _lib.AnirecError("TrainEngine.run is the single-GPU loop; use DistTrainEngine")
         if first_step is None:
             first_step = int(self.read_state()["step_fwd"])
         if n_steps is None:
@@ -260,6 +304,11 @@ class TrainEngine:
             self.stream.synchronize()
             self.lib.anirec_trainer_destroy(self._trainer)
             self._trainer = None
+        if self._stepper is not None:
+            self.stream.synchronize()
+            torch.cuda.synchronize(self.device)
+            self.lib.anirec_dist_stepper_destroy(self._stepper)
+            self._stepper = None
 
     def __del__(self):
         try:
@@ -278,10 +327,11 @@ def workspace_layout(max_batch, arena_steps):
     capC = (cap + cap // _lib.CHUNK + 2 + 3) & ~3
     off = 0
     lay = {"cap": cap, "capC": capC}
+    # hpart, pub, regpart, reghot, P, S hold two copies (step parity 0 then 1)
     for name, nbytes in (("su", 4 * cap), ("sa", 4 * cap), ("dy", 4 * cap),
-                         ("hpart", 4 * 8 * _lib.MAX_SEG * ((cap + 255) // 256)), ("pub", 64),
-                         ("regpart", 4 * 2 * _lib.ADAM_BLOCKS),
-                         ("P", 4 * 2 * capC * DIM), ("S", 4 * 2 * capC)):
+                         ("hpart", 2 * 4 * 8 * _lib.MAX_SEG * ((cap + 255) // 256)), ("pub", 2 * 64), ("sel", 16),
+                         ("regpart", 4 * 4 * _lib.ADAM_BLOCKS), ("reghot", 4 * 4 * _lib.HOT_BLOCKS_MAX),
+                         ("P", 2 * 4 * 2 * capC * DIM), ("S", 2 * 4 * 2 * capC)):
         lay[name] = (off, nbytes)
         off += _align(nbytes)
     a1 = _align(4 * 2 * cap)

@@ -111,15 +111,17 @@ def run_single(workload, steps, warmup, batch, use_graph=True, cpu_baseline=True
     assert int(rec["step_fwd"]) == warmup + steps and np.isfinite(rec["last_loss"])
 
     # instrumented pass: the same K steps' worth of work, stage by stage, HIP events on the
-    # engine's stream around every launch of each kernel
-    evs = {k: [] for k in ("fwd", "head", "bwd", "adam")}
+    # engine's stream around every launch of each kernel.  adam = hot (the rows batch t+1 touches + the step
+    # finish) then rest (every other row: the long HBM stream, the dominant kernel).
+    stages = ("fwd", "head", "bwd", "adam_hot", "adam_rest")
+    evs = {k: [] for k in stages}
     first = warmup + steps
     done = 0
     while done < steps:
-        blk = min(eng.arena_steps, steps - done)
-        eng.prep(first + done, blk)
+        blk = min(eng.arena_steps - 1, steps - done)
+        eng.prep(first + done, min(blk + 1, total_steps - (first + done)))    # hot(t) reads the slot of step t+1
         for _ in range(blk):
-            for name in ("fwd", "head", "bwd", "adam"):
+            for name in stages:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(eng.stream)
@@ -130,32 +132,41 @@ def run_single(workload, steps, warmup, batch, use_graph=True, cpu_baseline=True
     eng.synchronize()
     kern_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in evs.items()}
     rows = n_users + n_anime
+    # rows the rest launch streams = all rows minus the hot set (distinct rows of the NEXT batch), averaged over the
+    # instrumented steps (the last one has no next batch: its hot set is empty)
+    hot = []
+    for k in range(first + 1, min(first + steps + 1, total_steps)):
+        sl = slice(k * batch, (k + 1) * batch)
+        hot.append(int(torch.unique(ui[sl]).numel() + torch.unique(ai[sl]).numel()))
+    hot_rows = float(np.mean(hot + [0] * (steps - len(hot)))) if steps else 0.0
+    rest_bytes = ADAM_BYTES_PER_ELEM * (rows - hot_rows) * 128
     adam_bytes = ADAM_BYTES_PER_ELEM * rows * 128
-    adam_gbs = adam_bytes / (kern_ms["adam"] * 1e-3) / 1e9
-    # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (PMC cannot
-    # be collected from inside this process); only quoted for the workload it was measured on
+    rest_gbs = rest_bytes / (kern_ms["adam_rest"] * 1e-3) / 1e9
+    # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (PMC cannot be collected
+    # from inside this process); quoted only for the workload it was measured on AND only while the kernel source
+    # is still the one that was measured (git blob hash recorded next to the counters)
     traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_train_s109m.json")))
-        if workload == "s109m" and batch == 10_000:
-            traffic = pmc["k_adam"]["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    if workload == "s109m" and batch == 10_000:
+        traffic = pmc_traffic("train_s109m", "k_adam<true, true>", source="anirec_train.hip")
+    step_bytes = (FWD_BYTES_PER_RATING + BWD_BYTES_PER_RATING) * batch + adam_bytes
     out = {
         "value": steps * batch / dt,
         "ms_per_step": dt / steps * 1e3,
         "loss": float(rec["last_loss"]),
         "kernels_ms": kern_ms,
-        "roofline": {"kernel": "k_adam (dense fused Adam, both tables)", "bound": "hbm",
-                     "achieved": adam_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": adam_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": adam_bytes,
-                     "avg_launch_ms": kern_ms["adam"]},
+        "hot_rows_per_step": hot_rows,
+        "roofline": {"kernel": "k_adam<rest> (dense fused Adam over the %.0f rows the next batch does not touch; the "
+                               "other %.0f rows are updated by k_adam_hot)" % (rows - hot_rows, hot_rows),
+                     "bound": "hbm", "achieved": rest_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": rest_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": rest_bytes,
+                     "avg_launch_ms": kern_ms["adam_rest"]},
         # whole-step roofline of SURVEY.md §8(d): (3.1 KB x B + 28 B x table elements) / step time
-        "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_step": (FWD_BYTES_PER_RATING + BWD_BYTES_PER_RATING) * batch + adam_bytes,
-                          "achieved": ((FWD_BYTES_PER_RATING + BWD_BYTES_PER_RATING) * batch + adam_bytes) / (dt / steps) / 1e9,
-                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": ((FWD_BYTES_PER_RATING + BWD_BYTES_PER_RATING) * batch + adam_bytes) / (dt / steps) / 1e9 / HBM_PEAK_GBS},
+        "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_step": step_bytes,
+                          "achieved": step_bytes / (dt / steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS,
+                          # what the graph hides: sum of the five kernels run one after the other vs the step
+                          "serial_kernels_ms": float(sum(kern_ms.values()))},
         "fwd_gbs": FWD_BYTES_PER_RATING * batch / (kern_ms["fwd"] * 1e-3) / 1e9,
         "bwd_gbs": BWD_BYTES_PER_RATING * batch / (kern_ms["bwd"] * 1e-3) / 1e9,
     }
@@ -198,11 +209,28 @@ def cpu_baseline_port(n_users, n_anime, batch, budget_s=12.0):
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense bf16/f16 MFMA peak (MI355X_MICROARCH.md)
 
 
-def pmc_traffic(name, kernels=None):
-    """HBM bytes from the committed PMC passes (profiles/r01_pmc_traffic_<name>.json): per-launch mean of one
-    kernel, or the sum over the listed kernels of (mean bytes x launches per call); None if unavailable."""
+PMC_ROUND = "r02"
+
+
+def git_blob_hash(path):
+    """`git hash-object` of a file: sha1 over "blob <size>\\0" + content."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def pmc_traffic(name, kernels=None, source=None):
+    """HBM bytes from the committed PMC passes (profiles/<round>_pmc_traffic_<name>.json): per-launch mean of one
+    kernel, or the sum over the listed kernels of (mean bytes x launches per call).  The JSON records the git blob
+    hash of every csrc/*.hip at collection time; if `source` (the file holding the kernel) has changed since, the
+    counters no longer describe the kernel being timed and None is returned."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % name)))["kernels"]
+        rec = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (PMC_ROUND, name))))
+        if source is not None:
+            cur = git_blob_hash(os.path.join(ROOT, "anime_recommendations_amd", "csrc", source))
+            if rec.get("sources", {}).get(source) != cur:
+                return None
+        d = rec["kernels"]
         if isinstance(kernels, str):
             return d[kernels]["total_bytes_per_launch"]
         return sum(d[k]["total_bytes_per_launch"] * n for k, n in kernels.items())
@@ -210,84 +238,122 @@ def pmc_traffic(name, kernels=None):
         return None
 
 
-def run_cosine_topk(cpu_baseline=True):
-    """BASELINE.json configs[3]: row-normalise + all-pairs cosine + top-k (queries/s).
-    k = 10 is the reference's configured neighbour count (config/config.yaml:105 id_query_number,
-    :159 model_num_recs); k = 100 is kept as a stress case (10 x the candidate appends).
-    anime: every one of 18 000 rows is a query; users: 350 000 keys, a 65 536-query slice of the
-    all-pairs job (the full job is 5.3 such slices; throughput per query is the same)."""
+def _cosine_leg(W, nq, k, cpu_baseline, reps=3, slice_note=None, traffic_name=None):
+    """row-normalise + cosine top-k of `nq` query rows (rows 0..nq-1) against every row of W; queries/s of the whole
+    pipeline, the k_cand roofline from HIP events around its launches, and the rows that fell back to the exact path."""
     import torch
     from anime_recommendations_amd import ops
-    out = {}
-    for name, n, nq, k in (("anime_18k_allpairs_top10", 18_000, 18_000, 10),
-                           ("users_350k_keys_65536q_top10", 350_000, 65_536, 10),
-                           ("users_350k_keys_65536q_top100", 350_000, 65_536, 100)):
-        g = torch.Generator(device="cuda")
-        g.manual_seed(7)
-        W = torch.randn(n, 128, generator=g, device="cuda") * 0.05
-        q = torch.arange(nq, dtype=torch.int32, device="cuda")
+    n = W.shape[0]
+    q = torch.arange(nq, dtype=torch.int32, device="cuda")
+    Wh = ops.rownorm(W)
+    ops.cosine_topk_mfma(Wh, q, k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
         Wh = ops.rownorm(W)
-        ops.cosine_topk_mfma(Wh, q, k)
-        torch.cuda.synchronize()
-        reps = 5
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            Wh = ops.rownorm(W)
-            idx, sim, nfb = ops.cosine_topk_mfma(Wh, q, k)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
-        flops = 2.0 * nq * n * 128
-        tf = flops / dt / 1e12
-        # roofline leg: HIP events around the k_cand launches (on the stream they run on), one extra call
+        idx, sim, nfb = ops.cosine_topk_mfma(Wh, q, k)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    flops = 2.0 * nq * n * 128
+    # roofline leg: HIP events around the k_cand launches (on the stream they run on), one extra call; with more
+    # than 65 536 queries the op runs in query batches and the hook reports the LAST batch, so time batch by batch
+    cand_ms, cand_launches = 0.0, 0
+    for q0 in range(0, nq, 65536):
         ops.topk_mfma_timing(True)
-        ops.cosine_topk_mfma(Wh, q, k)
-        cand_ms, cand_launches = ops.topk_mfma_timing(False)
-        tfk = flops / (cand_ms * 1e-3) / 1e12
-        traffic = None      # HBM bytes of the k_cand launches of one call, from the PMC passes under profiles/
-        try:
-            if (n, nq, k) == (350_000, 65_536, 10):
-                traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_cosine_topk_350k_x_65536_k10.json")))[
-                    "hbm_traffic_k_cand_all_13_launches"]["total_bytes"]
-        except (OSError, KeyError, ValueError):
-            pass
-        rec = {"value": nq / dt, "unit": "queries/s", "ms": dt * 1e3, "k": k, "fallback_rows": int(nfb),
-               "pipeline_tflops": tf,
-               "roofline": {"kernel": "k_cand (v_mfma_f32_16x16x32_f16 scores + fused candidate filter), "
-                                      "%d super-step launches summed" % cand_launches,
-                            "bound": "mfma", "achieved": tfk, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": tfk / MFMA_F16_PEAK_TFLOPS, "kernel_ms": cand_ms, "traffic": traffic}}
-        if cpu_baseline and k == 10:
-            from oracle import c_oracle
-            Whn = Wh.cpu().numpy()
-            nqc = 256 if n < 50_000 else 32
-            t0 = time.perf_counter()
-            c_oracle.cosine_topk(Whn, np.arange(nqc, dtype=np.int32), k)
-            dtc = time.perf_counter() - t0
-            rec["cpu_baseline"] = {"value": nqc / dtc, "unit": "queries/s", "cores": c_oracle.max_threads(),
-                                   "kind": "port", "sample": "%d queries, plain-C dot + top-%d per query" % (nqc, k)}
-        out[name] = rec
-        if (n, nq, k) == (350_000, 65_536, 10):
-            # the whole similar-users job (every user a query: 5.3 such slices); bench.py --gpus N reports the
-            # same job sharded over N ranks (dist_bench.py)
-            qa = torch.arange(n, dtype=torch.int32, device="cuda")
-            ops.cosine_topk_mfma(Wh, qa, k)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                ops.cosine_topk_mfma(Wh, qa, k)
-            torch.cuda.synchronize()
-            dta = (time.perf_counter() - t0) / 3
-            out["users_350k_allpairs_top10"] = {"value": n / dta, "unit": "queries/s", "ms": dta * 1e3, "k": k,
-                                                "pipeline_tflops": 2.0 * n * n * 128 / dta / 1e12,
-                                                "roofline": {"kernel": "k_cand, 6 query slices", "bound": "mfma",
-                                                             "achieved": 2.0 * n * n * 128 / dta / 1e12,
-                                                             "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                                             "frac": 2.0 * n * n * 128 / dta / 1e12 / MFMA_F16_PEAK_TFLOPS,
-                                                             "traffic": None}}
-            del qa
-        del W, Wh, q
+        ops.cosine_topk_mfma(Wh, q[q0:q0 + 65536], k)
+        ms, nl = ops.topk_mfma_timing(False)
+        cand_ms += ms
+        cand_launches += nl
+    tfk = flops / (cand_ms * 1e-3) / 1e12
+    traffic = pmc_traffic(traffic_name, {"k_cand": 1}, source="anirec_topk_mfma.hip") if traffic_name else None
+    rec = {"value": nq / dt, "unit": "queries/s", "ms": dt * 1e3, "k": k, "n_keys": n, "n_queries": nq,
+           "fallback_rows": int(nfb), "pipeline_tflops": flops / dt / 1e12,
+           "roofline": {"kernel": "k_cand (v_mfma_f32_16x16x32_f16 scores + fused candidate filter), "
+                                  "%d launches summed" % cand_launches,
+                        "bound": "mfma", "achieved": tfk, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tfk / MFMA_F16_PEAK_TFLOPS, "kernel_ms": cand_ms,
+                        "pipeline_frac": flops / dt / 1e12 / MFMA_F16_PEAK_TFLOPS, "traffic": traffic}}
+    if slice_note:
+        rec["note"] = slice_note
+    if cpu_baseline:
+        from oracle import c_oracle
+        Whn = Wh.cpu().numpy()
+        nqc = 256 if n < 50_000 else 32
+        t0 = time.perf_counter()
+        c_oracle.cosine_topk(Whn, np.arange(nqc, dtype=np.int32), k)
+        dtc = time.perf_counter() - t0
+        rec["cpu_baseline"] = {"value": nqc / dtc, "unit": "queries/s", "cores": c_oracle.max_threads(),
+                               "kind": "port", "sample": "%d queries, plain-C dot + top-%d per query" % (nqc, k)}
+    del Wh, q
+    return rec
+
+
+def run_cosine_topk(cpu_baseline=True, trained=None):
+    """BASELINE.json configs[3] as written: row-normalise + ALL-PAIRS cosine + top-100 over the 18 k x 128 anime and
+    the 350 k x 128 user matrices (every row a query) — the headline legs.  k = 10, the reference's configured
+    neighbour count (config/config.yaml:105 id_query_number), is reported beside them.  Embeddings: N(0, 0.05^2)
+     and, when `trained` = (U, A) is given, the tables after one epoch of training on S7M."""
+    import torch
+    out = {}
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    Wu = torch.randn(350_000, 128, generator=g, device="cuda") * 0.05
+    Wa = torch.randn(18_000, 128, generator=g, device="cuda") * 0.05
+    out["anime_18k_allpairs_top100"] = _cosine_leg(Wa, 18_000, 100, cpu_baseline)
+    out["users_350k_allpairs_top100"] = _cosine_leg(Wu, 350_000, 100, cpu_baseline, reps=2,
+                                                    traffic_name="cosine_topk_k100")
+    out["anime_18k_allpairs_top10"] = _cosine_leg(Wa, 18_000, 10, False)
+    out["users_350k_allpairs_top10"] = _cosine_leg(Wu, 350_000, 10, False, reps=2)
+    out["users_350k_keys_65536q_top100"] = _cosine_leg(Wu, 65_536, 100, False,
+                                                       slice_note="one 65 536-query slice of the all-pairs job")
+    del Wu, Wa
+    torch.cuda.empty_cache()
+    if trained is not None:
+        U, A = (torch.as_tensor(x, device="cuda") for x in trained)
+        out["trained_s7m_anime_%d_allpairs_top100" % A.shape[0]] = _cosine_leg(A, A.shape[0], 100, False)
+        out["trained_s7m_users_%d_allpairs_top100" % U.shape[0]] = _cosine_leg(U, U.shape[0], 100, False)
+        del U, A
         torch.cuda.empty_cache()
     return out
+
+
+def run_s7m_epoch(use_graph=True):
+    """BASELINE.json configs[1] end to end: a 7 M-row user_stats.parquet-schema file (data.synth_user_stats,
+    SURVEY §8(d) S7M: 15 000 users x 17 560 anime) read back from disk, id-encoded on the GPU
+    (ingest.load_user_stats = get_df, neural_network.py:25-63) and trained for ONE epoch by trainer.fit
+    (model.fit, :210-217) with the reference's hyper-parameters.  Returns the record and the trained tables."""
+    import tempfile
+    import torch
+    from anime_recommendations_amd import data, ingest, trainer
+    t0 = time.perf_counter()
+    df = data.synth_user_stats(n_users=15_000, n_anime=17_560, n_ratings=7_000_000)
+    t_gen = time.perf_counter() - t0
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "user_stats.parquet")
+        df.to_parquet(path, index=False)
+        n_rows = len(df)
+        del df
+        t0 = time.perf_counter()
+        table = ingest.load_user_stats(path)
+        torch.cuda.synchronize()
+        t_load = time.perf_counter() - t0
+    cfg = trainer.FitConfig(epochs=1, verbose=0, use_graph=use_graph)
+    trainer.fit(table, trainer.FitConfig(epochs=1, verbose=0, use_graph=use_graph, test_size=len(table) - 20_000))  # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = trainer.fit(table, cfg)
+    torch.cuda.synchronize()
+    t_fit = time.perf_counter() - t0
+    n_train = len(table) - cfg.test_size
+    steps = (n_train + cfg.batch_size - 1) // cfg.batch_size
+    rec = {"value": n_train / t_fit, "unit": "ratings/s", "epoch_s": t_fit, "steps": steps,
+           "ms_per_step": t_fit / steps * 1e3, "rows": n_rows, "n_users": table.n_users, "n_anime": table.n_anime,
+           "loss": res.history["loss"][0], "val_loss": res.history["val_loss"][0],
+           "load_user_stats_s": t_load, "synth_generation_s": t_gen,
+           "what": "one epoch of trainer.fit (shuffle, %d steps of 10 000, hold-out validation, best-weights snapshot, "
+                   "weights copied back to the host) on a 7 M-row synthetic user_stats.parquet read through "
+                   "ingest.load_user_stats" % steps}
+    return rec, (res.U, res.A)
 
 
 def run_ingest(cpu_baseline=True):
@@ -337,7 +403,8 @@ def run_ingest(cpu_baseline=True):
                         "traffic": pmc_traffic("ingest", {"k_ing_alive": 1, "k_ing_insert": 1, "k_ing_count": 1,
                                                           "k_ing_user_filter<true>": 1, "k_ing_compact": 1,
                                                           "k_scan_reduce": 3, "k_scan_spine": 3, "k_scan_apply": 3,
-                                                          "k_enc_first": 2, "k_enc_flag": 2, "k_enc_emit": 2})}}
+                                                          "k_enc_first": 2, "k_enc_flag": 2, "k_enc_emit": 2},
+                                             source="anirec_ingest.hip")}}
     if cpu_baseline:
         import pandas as pd
         from oracle import ingest_oracle
@@ -454,7 +521,7 @@ def run_user_recs(cpu_baseline=True):
                                        "frac": fav_bytes / dt_f / 1e9 / HBM_PEAK_GBS, "traffic": None}},
            "roofline": {"kernel": "k_user_recs (one workgroup per query: 11 bit rows of 2.25 KB -> LDS counts -> top-10)",
                         "bound": "hbm", "achieved": rec_bytes / dt_r / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": rec_bytes / dt_r / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("recs", "k_user_recs")}}
+                        "frac": rec_bytes / dt_r / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("recs", "k_user_recs", source="anirec_recs.hip")}}
     if cpu_baseline:
         from oracle import recs_oracle
         nu_s = 2_000                                       # users 0..1999 of the same table
@@ -529,9 +596,10 @@ def run_predict_grid(cpu_baseline=True):
     dt = (time.perf_counter() - t0) / reps
     gbs = nq * n_a * 4 / dt / 1e9
     rec = {"value": nq * n_a / dt, "unit": "ratings/s", "ms": dt * 1e3,
-           "roofline": {"kernel": "k_predict_mfma (split-f16 MFMA + sigmoid head, fp32 grid written)", "bound": "hbm",
+           "roofline": {"kernel": "k_predict_mfma2 (split-f16 MFMA, anime as the row operand: 16-B non-temporal row-quad "
+                                  "stores, sigmoid + stores of a tile under the MFMAs of the next)", "bound": "hbm",
                         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                        "traffic": pmc_traffic("pgrid", "k_predict_mfma")}}
+                        "traffic": pmc_traffic("pgrid", "k_predict_mfma2", source="anirec_predict_mfma.hip")}}
     if cpu_baseline:
         from oracle import c_oracle
         Un, An = U[:4096].cpu().numpy(), A.cpu().numpy()
@@ -577,7 +645,7 @@ def main():
         "roofline": res["roofline"],
         "step_roofline": res["step_roofline"],
         "cpu_baseline": res.get("cpu_baseline"),
-        "kernels_ms": res["kernels_ms"],
+        "kernels_ms": res["kernels_ms"], "hot_rows_per_step": res["hot_rows_per_step"],
         "embed_fwd_GBps": res["fwd_gbs"], "embed_bwd_GBps": res["bwd_gbs"],
         "final_loss": res["loss"],
     }
@@ -585,11 +653,21 @@ def main():
         other = "s7m" if args.workload == "s109m" else "s109m"
         r2 = run_single(other, args.steps, args.warmup, args.batch, use_graph=not args.no_graph,
                         cpu_baseline=not args.no_cpu_baseline)
-        line["also"] = {other: {"value": r2["value"], "unit": "ratings/s", "ms_per_step": r2["ms_per_step"],
-                                "roofline": r2["roofline"], "kernels_ms": r2["kernels_ms"],
-                                "cpu_baseline": r2.get("cpu_baseline")}}
-    if not args.no_also:
-        line["also"]["cosine_topk"] = run_cosine_topk(cpu_baseline=not args.no_cpu_baseline)
+        line["also"] = {}
+        shape_rec = {"value": r2["value"], "unit": "ratings/s", "ms_per_step": r2["ms_per_step"],
+                     "roofline": r2["roofline"], "step_roofline": r2["step_roofline"], "kernels_ms": r2["kernels_ms"],
+                     "cpu_baseline": r2.get("cpu_baseline"),
+                     "what": "%d steps on the %s table shape, i.i.d. synthetic batches resident in HBM" % (args.steps, other)}
+        trained = None
+        if other == "s7m":
+            # configs[1]: the real thing first (a 7 M-row file through get_df -> model.fit), the table-shape
+            # micro-benchmark (same kernels, no epoch bookkeeping) beside it
+            epoch_rec, trained = run_s7m_epoch(use_graph=not args.no_graph)
+            epoch_rec["table_shape_microbench"] = shape_rec
+            line["also"]["s7m"] = epoch_rec
+        else:
+            line["also"][other] = shape_rec
+        line["also"]["cosine_topk"] = run_cosine_topk(cpu_baseline=not args.no_cpu_baseline, trained=trained)
         line["also"]["predict_grid_100k_x_18k"] = run_predict_grid(cpu_baseline=not args.no_cpu_baseline)
         line["also"]["predict_topk_100k_users_x_18k"] = run_predict_topk(cpu_baseline=not args.no_cpu_baseline)
         line["also"]["embed_fwd_gather_4M_pairs"] = run_gather_roofline()

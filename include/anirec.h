@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ANIREC_ABI_VERSION 1
+#define ANIREC_ABI_VERSION 2
 #define ANIREC_DIM 128          /* embedding width (floats) */
 #define ANIREC_MAX_BATCH 16384  /* ratings per rank per step handled by one sort workgroup */
 #define ANIREC_CHUNK 32         /* max gradient contributions summed by one half-wave */
@@ -99,17 +99,24 @@ typedef struct anirec_train_desc {
   int32_t n_anime_rows; /* anime rows (replicated) */
   int32_t max_batch;    /* capacity of per-step buffers, 1..ANIREC_MAX_BATCH */
   int32_t arena_steps;  /* number of steps the prep arena holds */
-  int32_t anime_dense;  /* 0: anime gradient stays chunked (1 GPU); 1: bwd writes the dense
-                           buffer `anime_grad`, the caller all-reduces it (RCCL), adam reads it */
+  int32_t dense_mode;   /* 0: one GPU, gradients stay chunked.
+                           1: user-sharded data parallelism — bwd also writes the ANIME rows' gradient into
+                              `dense_grad`, the caller all-reduces it (RCCL), adam reads it;
+                           2: replicated tables (the reference's TPUStrategy shape, neural_network.py:173-178)
+                              — EVERY row's gradient goes through `dense_grad` (all-reduce, or reduce-scatter
+                              with adam_row_lo/hi = this rank's row shard) */
   int32_t n_seg;        /* head packets to read: 1 on one GPU, world size when all-gathered */
   int32_t my_seg;       /* this rank's packet */
-  int32_t pad0;
+  int32_t dense_rows;   /* rows of dense_grad: >= the rows it carries (n_anime_rows in mode 1, all rows in
+                           mode 2); extra rows are zero padding up to a multiple of the world size */
   float l2;             /* lambda of embeddings_regularizer L2 (neural_network.py:73) */
-  float pad1;
+  int32_t adam_row_lo;  /* mode 2: adam updates table rows [adam_row_lo, adam_row_hi) only (the caller */
+  int32_t adam_row_hi;  /* all-gathers W afterwards); 0,0 = every row */
+  int32_t pad1;
   /* tables: rows [0,n_user_rows) users, then n_anime_rows anime; [rows][128] fp32.
    * W = embeddings, M/V = Adam first/second moments. */
   float *W, *M, *V;
-  int32_t *rowmap;      /* [n_user_rows+n_anime_rows]; zero before first use, left zero */
+  int32_t *rowmap;      /* [2][n_user_rows+n_anime_rows] (one map per step parity); zero before first use, left zero */
   anirec_state *state;
   /* this rank's ratings in epoch (shuffled) order; user_idx are LOCAL user rows */
   const int32_t *user_idx;
@@ -121,8 +128,8 @@ typedef struct anirec_train_desc {
   /* head packets: n_seg packets of anirec_packet_floats(max_batch) floats each; packet
    * my_seg is written by the fwd kernel, the others by the caller's all-gather. */
   float *packets;
-  float *anime_grad;    /* [n_anime_rows*128 + n_anime_rows] or NULL */
-  void *workspace;      /* >= anirec_train_workspace_bytes(max_batch, arena_steps) */
+  float *dense_grad;    /* [dense_rows*128] gradients then [dense_rows] self-coefficient sums, or NULL */
+  void *workspace;      /* >= anirec_train_workspace_bytes(max_batch, arena_steps); zero before first use */
   size_t workspace_bytes;
 } anirec_train_desc;
 
@@ -140,8 +147,9 @@ int anirec_train_init_reg(const anirec_train_desc *d, void *stream);
  * unsorted_segment_sum densification inside model.fit. */
 int anirec_train_prep(const anirec_train_desc *d, int32_t first_step, int32_t n_steps, void *stream);
 
-/* The four stages of one step.  They read the step index from state->step_fwd /
- * state->step_bwd so that a captured graph can be replayed for every step:
+/* The four stages of one step.  They read the step index from device memory (state->step_fwd /
+ * state->step_bwd / a workspace word head publishes) so that a captured graph can be replayed for every step;
+ * the per-step scratch is double-buffered by step parity:
  *   fwd  : gather U[ui], A[ai]; c = <l2n(u), l2n(a)>      -> packet, su, sa
  *   head : Dense(1) + BatchNorm(batch stats over ALL packets) + sigmoid + BCE,
  *          d loss / d y per rating and the batch partial sums
@@ -154,14 +162,30 @@ int anirec_train_fwd(const anirec_train_desc *d, void *stream);
 int anirec_train_head(const anirec_train_desc *d, void *stream);
 int anirec_train_bwd(const anirec_train_desc *d, void *stream);
 int anirec_train_adam(const anirec_train_desc *d, void *stream);
-/* adam in two launches so the user rows (which == 1) can be updated while the anime gradient is
- * still in the all-reduce; which == 2 updates the anime rows and finishes the step. */
+/* adam as two launches.
+ *   dense_mode 1: which == 1 updates the user rows (may run while the anime gradient is still in the
+ *     all-reduce), which == 2 the anime rows and finishes the step.
+ *   dense_mode 0: which == 3 ("hot") updates the rows the NEXT batch touches (the prepared slot of step t+1)
+ *     and finishes the step; which == 4 ("rest") every other row.  fwd/head/bwd of step t+1 only read hot rows,
+ *     so they may run beside the rest launch — anirec_trainer_run's graph does exactly that. */
 int anirec_train_adam_part(const anirec_train_desc *d, int32_t which, void *stream);
+
+/* Multi-GPU step as three C calls and two collectives (dense_mode 1 or 2; the stepper owns a side stream):
+ *     anirec_train_fwd                      -> all-gather of the head packets (BatchNorm sees the global batch)
+ *     anirec_dist_step_mid  (head, bwd, densify; mode 1 forks the user-row adam onto the side stream)
+ *                                           -> all-reduce / reduce-scatter of dense_grad
+ *     anirec_dist_step_back (joins the side stream; adam of the rows that needed the collective; step finish)
+ *   [mode 2 with a row shard: all-gather of W] */
+typedef struct anirec_dist_stepper anirec_dist_stepper;
+int anirec_dist_stepper_create(const anirec_train_desc *d, anirec_dist_stepper **out_host);
+int anirec_dist_stepper_destroy(anirec_dist_stepper *h);
+int anirec_dist_step_mid(anirec_dist_stepper *h, void *stream);
+int anirec_dist_step_back(anirec_dist_stepper *h, void *stream);
 
 /* Steps [first_step, first_step + n_steps) — prep, fwd, head, bwd, adam — on one GPU; first_step
  * must equal the device cursor state->step_fwd.  use_graph != 0 replays a captured hipGraph of
  * G = min(32, arena_steps/2) steps whose first node prepares the G steps after it, so no host
- * work is needed between replays. */
+ * work is needed between replays; inside the graph rest(t) and fwd/head/bwd(t+1) are parallel branches. */
 typedef struct anirec_trainer anirec_trainer; /* host-side handle: descriptor copy + graph cache */
 int anirec_trainer_create(const anirec_train_desc *d, anirec_trainer **out_host);
 int anirec_trainer_destroy(anirec_trainer *t);

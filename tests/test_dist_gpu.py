@@ -1,7 +1,10 @@
-"""GPU test of the multi-GPU path with the REAL HIP stages: two ranks share cuda:0 and talk over
-gloo (RCCL needs one GPU per rank; the driver exercises that on the 8-GPU node).  The two-rank
-result must match the oracle stepping on the global batches, and the replicated anime table
-must stay bit-identical across ranks."""
+"""GPU tests of the multi-GPU path with the REAL HIP step halves.
+  * two ranks share cuda:0 and talk over gloo, in each of the three data-parallel modes: the result must match the
+    oracle stepping on the global batches and the replicated tables must stay bit-identical across ranks;
+  * backend "nccl" (= RCCL), world size 1, ANIREC_DIST_LOOP=1: the N>1 loop — all_gather_into_tensor, all_reduce /
+    reduce_scatter_tensor on the engine's stream, the forked user-row Adam — runs on hardware and must equal the
+    single-engine run bit for bit;
+  * two ranks on two GPUs over RCCL when the box has two (skipped on a one-GPU box; the driver's 8-GPU node runs it)."""
 import os
 import socket
 
@@ -27,15 +30,19 @@ def _problem():
     return U, A, ui, ai, t, rng.permutation(n)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mode="sharded", backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:%d" % (rank if backend == "nccl" else 0))
+    if backend == "nccl":
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from anime_recommendations_amd import schedule
         from anime_recommendations_amd.dist import DistTrainEngine
         U, A, ui, ai, t, perm = _problem()
-        dev = torch.device("cuda:0")
-        eng = DistTrainEngine(U.shape[0], A.shape[0], 1000, l2=1e-4, arena_steps=4, device=dev)
+        eng = DistTrainEngine(U.shape[0], A.shape[0], 1000, l2=1e-4, arena_steps=4, device=dev, mode=mode)
         eng.set_head(w=1.2)
         eng.set_weights(U, A)
         tu, ta, tt, tp = (torch.from_numpy(np.asarray(x)).to(dev) for x in (ui, ai, t, perm))
@@ -47,9 +54,11 @@ def _worker(rank, world, port, out_dir):
         vl, vm = eng.evaluate(tu[:500], ta[:500], tt[:500])
         Ufull = eng.U.cpu().numpy()
         Aloc = eng.A.cpu()
-        a_all = [torch.empty_like(Aloc) for _ in range(world)]
-        dist.all_gather(a_all, Aloc)
-        assert all((x == a_all[0]).all() for x in a_all)
+        for tbl in ([eng.A] if mode == "sharded" else [eng.A, eng.eng.U]):
+            tbl = tbl.contiguous() if backend == "nccl" else tbl.cpu()
+            a_all = [torch.empty_like(tbl) for _ in range(world)]
+            dist.all_gather(a_all, tbl)
+            assert all((x == a_all[0]).all() for x in a_all)
         if rank == 0:
             rec = eng.read_state()
             np.savez(os.path.join(out_dir, "dist.npz"), U=Ufull, A=Aloc.numpy(), loss=loss, mse=mse, vl=vl, vm=vm,
@@ -59,12 +68,15 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_match_oracle_on_global_batches(tmp_path):
+def _port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    return port
+
+
+def _check_against_oracle(tmp_path):
     d = np.load(tmp_path / "dist.npz")
     U, A, ui, ai, t, perm = _problem()
     st = orc.new_state(U, A, orc.new_head(w=1.2))
@@ -85,3 +97,70 @@ def test_two_ranks_on_one_gpu_match_oracle_on_global_batches(tmp_path):
     assert abs(float(d["loss"]) - sum(losses) / sum(ns)) < 5e-6
     ev = orc.evaluate(st, ui[:500], ai[:500], t[:500])
     assert abs(float(d["vl"]) - float(ev["val_loss"])) < 5e-6 and abs(float(d["vm"]) - float(ev["val_mse"])) < 1e-6
+
+
+@pytest.mark.parametrize("mode", ["sharded", "replicated", "replicated_rs"])
+def test_two_ranks_on_one_gpu_match_oracle_on_global_batches(tmp_path, mode):
+    mp.spawn(_worker, args=(2, _port(), str(tmp_path), mode), nprocs=2, join=True)
+    _check_against_oracle(tmp_path)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: two GPUs")
+@pytest.mark.parametrize("mode", ["sharded", "replicated_rs"])
+def test_two_ranks_on_two_gpus_over_rccl_match_oracle(tmp_path, mode):
+    mp.spawn(_worker, args=(2, _port(), str(tmp_path), mode, "nccl"), nprocs=2, join=True)
+    _check_against_oracle(tmp_path)
+
+
+def _nccl_world1_worker(rank, port, out_dir):
+    """The N>1 step loop under the backend it ships with: RCCL, one rank, ANIREC_DIST_LOOP=1."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      ANIREC_DIST_LOOP="1")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from anime_recommendations_amd import schedule
+        from anime_recommendations_amd.dist import DistTrainEngine
+        from anime_recommendations_amd.engine import TrainEngine
+        U, A, ui, ai, t, perm = _problem()
+        tu, ta, tt, tp = (torch.from_numpy(np.asarray(x)).to(dev) for x in (ui, ai, t, perm))
+        B = 2000
+        n_steps = (len(perm) + B - 1) // B
+        alphas = schedule.adam_alphas(3e-5, 1, n_steps)
+        # the single-engine run (hot + rest launches, no collectives) on the same batches
+        ref = TrainEngine(U.shape[0], A.shape[0], max_batch=B, arena_steps=4, device=dev)
+        ref.set_head(w=1.2)
+        ref.set_weights(U, A)
+        starts = np.arange(n_steps) * B
+        counts = np.minimum(B, len(perm) - starts)
+        ref.set_epoch(tu[tp], ta[tp], tt[tp], starts, counts, alphas)
+        ref.run(n_steps, use_graph=False)
+        rref = ref.read_state()
+        out = {}
+        for mode in ("sharded", "replicated", "replicated_rs"):
+            eng = DistTrainEngine(U.shape[0], A.shape[0], B, l2=1e-4, arena_steps=4, device=dev, mode=mode)
+            assert eng.loop and eng.eng.dense_mode == (1 if mode == "sharded" else 2)
+            eng.set_head(w=1.2)
+            eng.set_weights(U, A)
+            eng.set_epoch_global(tu, ta, tt, tp, alphas)
+            eng.reset_metrics()
+            eng.run(n_steps)
+            rec = eng.read_state()
+            assert int(rec["step_fwd"]) == n_steps
+            # every row sees the same fp32 operations in the same order: bit-identical tables and Adam state
+            assert torch.equal(eng.eng.W, ref.W), mode
+            assert torch.equal(eng.eng.M, ref.M) and torch.equal(eng.eng.V, ref.V), mode
+            for k in ("w", "b", "gamma", "beta", "mov_mean", "mov_var"):
+                assert rec[k] == rref[k], (mode, k)
+            assert abs(float(rec["last_loss"]) - float(rref["last_loss"])) < 2e-6
+            out[mode] = eng.epoch_metrics()[0]
+            eng.close()
+        assert max(out.values()) - min(out.values()) < 2e-6
+        ref.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_nccl_world1_dist_loop_equals_single_engine_bitwise(tmp_path):
+    mp.spawn(_nccl_world1_worker, args=(_port(), str(tmp_path)), nprocs=1, join=True)

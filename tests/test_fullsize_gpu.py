@@ -49,6 +49,49 @@ def test_s109m_shape_training_is_deterministic_and_untouched_rows_are_bit_exact(
     assert (W1[untouched] == w).all() and (M1[untouched] == m).all() and (V1[untouched] == v).all()
 
 
+def _train_s7m(steps, use_graph):
+    import bench
+    from anime_recommendations_amd.engine import TrainEngine
+    from anime_recommendations_amd import schedule
+    n_u, n_a = bench.WORKLOADS["s7m"]
+    dev = torch.device("cuda:0")
+    ui, ai, t = bench.synth_ratings(n_u, n_a, steps * B, dev, seed=3)
+    U, A = bench.init_tables(n_u, n_a, dev)
+    eng = TrainEngine(n_u, n_a, max_batch=B, arena_steps=64)
+    eng.set_head(w=1.2)
+    eng.set_weights(U, A)
+    eng.set_epoch(ui, ai, t, np.arange(steps) * B, np.full(steps, B), schedule.adam_alphas(1e-5, 1, steps))
+    eng.run(steps, use_graph=use_graph)
+    eng.synchronize()
+    out = (eng.W.cpu().numpy(), eng.M.cpu().numpy(), eng.V.cpu().numpy(), eng.read_state(),
+           eng.rowmap.cpu().numpy())
+    eng.close()
+    return out, A.cpu().numpy(), ai.cpu().numpy()
+
+
+def test_s7m_shape_graph_overlap_is_bitwise_the_serial_run_and_untouched_rows_are_bit_exact():
+    """BASELINE configs[1] table shape (15 000 x 17 560, B = 10 000): ~40 % of the rows are touched by the NEXT
+    batch, so the graph's second branch (fwd/head/bwd of step t+1 beside the rest launch of step t) is exercised
+    hard — any row read before its update, or scratch overwritten too early, changes bits."""
+    steps = 70                                         # two 32-step graph replays + a 6-step tail
+    (W0, M0, V0, rec0, rm0), A0, ai = _train_s7m(steps, use_graph=False)
+    assert (rm0 == 0).all() and np.isfinite(rec0["last_loss"]) and int(rec0["step_fwd"]) == steps
+    for _ in range(2):
+        (W1, M1, V1, rec1, rm1), _, _ = _train_s7m(steps, use_graph=True)
+        assert (W1 == W0).all() and (M1 == M0).all() and (V1 == V0).all() and (rm1 == 0).all()
+        assert rec1["loss_wsum"] == rec0["loss_wsum"] and rec1["w"] == rec0["w"] and rec1["mov_var"] == rec0["mov_var"]
+    # anime rows no batch touched only see g = 2*l2*W: bit for bit the oracle's Adam
+    n_u = 15_000
+    untouched = np.setdiff1d(np.arange(A0.shape[0]), np.unique(ai))[:3000]
+    assert len(untouched) > 100
+    w = A0[untouched].copy()
+    m = np.zeros_like(w)
+    v = np.zeros_like(w)
+    for step in range(steps):
+        orc.adam_update(w, m, v, np.float32(2e-4) * w, orc.adam_alpha(1e-5, step + 1))
+    assert (W0[n_u + untouched] == w).all() and (M0[n_u + untouched] == m).all() and (V0[n_u + untouched] == v).all()
+
+
 def test_350k_neighbour_lists_properties_and_sample_equals_exact_path():
     from anime_recommendations_amd import ops
     g = torch.Generator(device="cuda")

@@ -101,7 +101,7 @@ def test_forward_and_head_match_oracle():
                         dtype=[("i", "<i4", (4,)), ("f", "<f4", (10,))])[0]
     assert list(pub["i"]) == [0, B, nblk, 0]
     assert abs(pub["f"][1] - f["mu"]) < 1e-6 and abs(pub["f"][2] - f["var"]) < 1e-7
-    assert abs(pub["f"][8] + pub["f"][9] - met["reg"]) / met["reg"] < 1e-6
+    assert abs(pub["f"][8] - 1e-4) < 1e-10        # lambda rides in the step constants; the L2 SUM is taken at the finish
     # bwd + adam finish the step: scalar state and History metrics
     eng.prep(0, 1)
     eng.bwd()
