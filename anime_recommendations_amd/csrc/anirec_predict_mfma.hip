@@ -68,6 +68,7 @@ struct PredArgs {
   const uint4 *Ub;  // [n_users][32] 16-B chunks: 16 hi chunks then 16 lo chunks per row
   const uint4 *Ab;  // [n_anime][32]
   int n_users, n_anime;
+  int tiles_per_part;  // k_predict_mfma2: blockIdx.y walks anime tiles [y * tiles_per_part, (y+1) * tiles_per_part)
   float hs, hb;     // sigmoid(c * hs + hb); hs already carries the 2^-16 of the operand scaling
   float *out;       // [n_users][n_anime]
 };
@@ -157,8 +158,12 @@ __global__ __launch_bounds__(256, 2) void k_predict_mfma(PredArgs a) {
 // k_predict_mfma2: the same grid with the operand roles swapped and a pipelined epilogue.
 //   * v_mfma_f32_16x16x32_f16 with the ANIME rows as the A (row) operand and the users as the B (column)
 //     operand: a lane's four accumulator registers of a 16x16 block are four CONSECUTIVE anime of ONE user,
-//     so the epilogue is one 16-byte store per block (8 per tile and wave, 16 users x 64 B each) instead of
-//     32 dword stores; the stores are non-temporal buffer stores (the 7.2 GB grid is written once) whose
+//     i.e. one 16-byte piece of an output row.  Stored as they stand (16 users x 64 B per instruction) the
+//     store path tops out at 3.1 TB/s; the SHAPE of a store instruction is what counts (probed on the GPU:
+//     4 rows x 256 B, 2 x 512 B and 1 x 1 KiB per instruction all reach 4.4 TB/s), so the 16 pieces of a
+//     user's 64 anime cross a wave-private, XOR-swizzled 4 KB LDS image (4 ds_write_b128 + 4 ds_read_b128 per
+//     16 users, no barrier: a wave's LDS operations execute in order) and leave as 4 rows x 256 B per
+//     instruction: 8 non-temporal 16-byte buffer stores per tile and wave instead of 32 dword stores, whose
 //     range check drops rows past n_users and columns past n_anime without branches.
 //   * the anime tile goes global -> LDS by LDS-DMA (no staging registers), two tiles resident;
 //   * sigmoid + store of tile t-1 are interleaved with the 96 MFMAs of tile t (second accumulator set):
@@ -172,12 +177,19 @@ struct Acc2 {
   f32x4 c[4][2];  // [anime block of 16][user block of 16]
 };
 
+// kDbg (timing only, wrong output): 1 = epilogue + stores without the MFMAs, 2 = MFMAs without the stores
+template <int kDbg>
 __global__ __launch_bounds__(256, 2) void k_predict_mfma2(PredArgs a) {
-  __shared__ __attribute__((aligned(16))) uint4 Ks[2][kPN * 32];  // 2 x 32 KB: hi+lo planes of 64 anime rows
+  // one LDS array (a second object beside an LDS-DMA target makes hipcc drain vmcnt before every ds_read):
+  // 2 x 32 KB key tiles (hi+lo planes of 64 anime rows), then 4 x 4 KB output staging (one per wave)
+  __shared__ __attribute__((aligned(16))) uint4 Ks[2 * kPN * 32 + 4 * 256];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c16 = lane & 15, gq = lane >> 4;
   const int u0 = blockIdx.x * kPM;
   const int wu = __builtin_amdgcn_readfirstlane(w);
+  // staging image of 16 users x 64 anime fp32: row = user (256 B = 16 slots of 16 B), slot ^= row (conflict-free
+  // ds_write_b128 of the accumulator layout and ds_read_b128 of whole rows)
+  uint4 *const stg = &Ks[2 * kPN * 32 + 256 * w];
 
   // B operand: user (16 ub + c16) of the wave's 32, k = 32 kk + 8 gq + j
   f16x8 uh[2][4], ul[2][4];
@@ -206,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void k_predict_mfma2(PredArgs a) {
     doff[i] = (uint32_t)(r * 512 + ((sl & 16) + ((sl & 15) ^ (r & 15))) * 16);
   }
   const uint32_t ks_base =
-      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&Ks[0][0] + (uint32_t)wu * 8192u;
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&Ks[0] + (uint32_t)wu * 8192u;
   auto dma_tile = [&](int t, int buf) {
     const char *base = reinterpret_cast<const char *>(a.Ab) + (size_t)t * (kPN * 512);
     const uint32_t l0 = ks_base + (uint32_t)buf * (kPN * 512);
@@ -221,22 +233,25 @@ __global__ __launch_bounds__(256, 2) void k_predict_mfma2(PredArgs a) {
   const f16x8 *ka[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk)
-    ka[kk] = reinterpret_cast<const f16x8 *>(&Ks[0][c16 * 32 + ((4 * kk + gq) ^ c16)]);
+    ka[kk] = reinterpret_cast<const f16x8 *>(&Ks[c16 * 32 + ((4 * kk + gq) ^ c16)]);
 
   // output: per-workgroup buffer descriptor over rows [u0, u0 + valid rows): rows past n_users and the byte
   // offset 0xFFFFFFF0 used for columns past n_anime fail the range check and are dropped by the hardware
   const int rows_valid = min(kPM, a.n_users - u0);
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       a.out + (size_t)u0 * a.n_anime, 0, (int)((size_t)rows_valid * a.n_anime * 4), 0x00020000);
-  uint32_t vrow[2];
-#pragma unroll
-  for (int ub = 0; ub < 2; ++ub) vrow[ub] = (uint32_t)((32 * w + 16 * ub + c16) * a.n_anime + 4 * gq) * 4u;
+  // store instruction j of user block ub: lane -> row 4 j + gq of the block, 16-byte piece c16 of its 256 B
+  const uint32_t vrow = (uint32_t)((32 * w + gq) * a.n_anime + 4 * c16) * 4u;
+  const uint32_t vrow4 = (uint32_t)(4 * a.n_anime) * 4u;
   // sigmoid(c * hs + hb) = 1 / (1 + 2^(c * nhs + nhb))
   const float nhs = -a.hs * 1.44269504088896341f, nhb = -a.hb * 1.44269504088896341f;
 
-  const int ntiles = (a.n_anime + kPN - 1) / kPN;
-  dma_tile(0, 0);
-  if (ntiles > 1) dma_tile(1, 1);
+  // this workgroup's anime tiles [tb, tb + ntiles): the grid's y dimension cuts the anime table into parts so that
+  // there are several times more workgroups than the 512 the chip holds and the dispatcher balances the tail
+  const int tb = blockIdx.y * a.tiles_per_part;
+  const int ntiles = min(a.tiles_per_part, (a.n_anime + kPN - 1) / kPN - tb);
+  dma_tile(tb, 0);
+  if (ntiles > 1) dma_tile(tb + 1, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -253,22 +268,39 @@ __global__ __launch_bounds__(256, 2) void k_predict_mfma2(PredArgs a) {
           f32x4 c = nxt.c[ab][ub];
           if (kk == 0) c = (f32x4){0.f, 0.f, 0.f, 0.f};
           // small terms first: lo*hi + hi*lo, then hi*hi
-          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, uh[ub][kk], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ul[ub][kk], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, uh[ub][kk], c, 0, 0, 0);
+          if (kDbg != 1) {
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, uh[ub][kk], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ul[ub][kk], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, uh[ub][kk], c, 0, 0, 0);
+          } else {
+            c[0] += ah[0] + al[1];
+          }
           nxt.c[ab][ub] = c;
         }
         if (epi && (kk & 1)) {  // 8 epilogue blocks per tile, one after every 12 MFMAs
-          const int eb = 2 * ab + (kk >> 1);  // 0..7 -> (anime block eb >> 1, user block eb & 1)
-          const int eab = eb >> 1, eub = eb & 1;
+          const int eb = 2 * ab + (kk >> 1);  // 0..7 -> user block eb >> 2, anime block eb & 3
+          const int eub = eb >> 2, eab = eb & 3;
           const f32x4 v = cur.c[eab][eub];
           f32x4 o;
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             o[i] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(v[i], nhs, nhb)));
-          const int col = tc * kPN + 16 * eab + 4 * gq;
-          const uint32_t voff = col < a.n_anime ? vrow[eub] + (uint32_t)(tc * kPN + 16 * eab) * 4u : 0xFFFFFFF0u;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsrc, voff, 0, 2 /* nt */);
+          // piece (anime block eab, quad gq) of user c16
+          stg[c16 * 16 + ((4 * eab + gq) ^ c16)] = __builtin_bit_cast(uint4, o);
+          if (eab == 3) {  // the user block is complete: 4 rows x 256 B per store instruction
+            const bool in = tc * kPN + 4 * c16 < a.n_anime;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int row = 4 * j + gq;
+              const u32x4 d = __builtin_bit_cast(u32x4, stg[row * 16 + (c16 ^ row)]);
+              const uint32_t voff = in ? vrow + (uint32_t)(16 * eub + 4 * j) * (vrow4 / 4u) + (uint32_t)(tc * kPN) * 4u
+                                       : 0xFFFFFFF0u;
+              if (kDbg != 2)
+                __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, voff, 0, 2 /* nt */);
+              else
+                asm volatile("" ::"v"(d));
+            }
+          }
         }
       }
     }
@@ -276,22 +308,22 @@ __global__ __launch_bounds__(256, 2) void k_predict_mfma2(PredArgs a) {
   Acc2 accA, accB;
   step(accA, accA, 0, 0, false);
   __syncthreads();  // everyone is done with buffer 0
-  int t = 1;
+  int t = 1;        // tile index relative to tb
   for (; t + 1 < ntiles; t += 2) {
-    if (t + 1 < ntiles) dma_tile(t + 1, 0);
-    step(accB, accA, 1, t - 1, true);
+    if (t + 1 < ntiles) dma_tile(tb + t + 1, 0);
+    step(accB, accA, 1, tb + t - 1, true);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the tile landed; the 8 younger stores stay in flight
     __syncthreads();
-    if (t + 2 < ntiles) dma_tile(t + 2, 1);
-    step(accA, accB, 0, t, true);
+    if (t + 2 < ntiles) dma_tile(tb + t + 2, 1);
+    step(accA, accB, 0, tb + t, true);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __syncthreads();
   }
   if (t < ntiles) {  // one tile left (in buffer 1), results of tile t-1 in accA
-    step(accB, accA, 1, t - 1, true);
-    step(accA, accB, 0, t, true);  // MFMAs on stale buffer 0 are thrown away; only the epilogue of tile t matters
+    step(accB, accA, 1, tb + t - 1, true);
+    step(accA, accB, 0, tb + t, true);  // MFMAs on stale buffer 0 are thrown away; only the epilogue of tile t matters
   } else {           // results of the last tile in accA
-    step(accB, accA, 0, t - 1, true);
+    step(accB, accA, 0, tb + t - 1, true);
   }
 }
 
@@ -335,14 +367,33 @@ int anirec_predict_grid_mfma(const float *U, const float *A, int32_t n_anime, co
   pa.Ab = (const uint4 *)Ab;
   pa.n_users = n_users;
   pa.n_anime = n_anime;
+  pa.tiles_per_part = 0;
   head_affine_mfma(head, &pa.hs, &pa.hb);
   pa.out = out;
   // 16-byte row quads need n_anime % 4 == 0 and 32-bit byte offsets inside a workgroup's 128 rows
   const char *ver = getenv("ANIREC_PREDICT_KERNEL");  // "1": force the dword-store kernel (A/B on one box)
   const bool v2 = (n_anime % 4 == 0) && ((size_t)n_anime * kPM * 4 < ((size_t)1 << 31)) && !(ver && ver[0] == '1');
-  if (v2)
-    hipLaunchKernelGGL(k_predict_mfma2, dim3((n_users + kPM - 1) / kPM), dim3(256), 0, s, pa);
-  else
+  if (v2) {
+    // anime parts: enough workgroups (>= ~8 per resident slot) for the dispatcher to balance the tail, parts of at
+    // least 16 tiles so the pipeline fill of a part stays a few per cent
+    const int ub = (n_users + kPM - 1) / kPM, ntile = n_pad / kPN;
+    const char *pe = getenv("ANIREC_PREDICT_PARTS");
+    int parts = pe ? atoi(pe) : (4096 + ub - 1) / ub;
+    if (parts > ntile / 16) parts = ntile / 16;
+    if (parts < 1) parts = 1;
+    pa.tiles_per_part = (ntile + parts - 1) / parts;
+    parts = (ntile + pa.tiles_per_part - 1) / pa.tiles_per_part;
+    const dim3 grid(ub, parts);
+    const char *dbg = getenv("ANIREC_PREDICT_DEBUG");
+    const int mode = dbg ? atoi(dbg) : 0;
+    if (mode == 1)
+      hipLaunchKernelGGL(k_predict_mfma2<1>, grid, dim3(256), 0, s, pa);
+    else if (mode == 2)
+      hipLaunchKernelGGL(k_predict_mfma2<2>, grid, dim3(256), 0, s, pa);
+
+    else
+      hipLaunchKernelGGL(k_predict_mfma2<0>, grid, dim3(256), 0, s, pa);
+  } else
     hipLaunchKernelGGL(k_predict_mfma, dim3((n_users + kPM - 1) / kPM), dim3(256), 0, s, pa);
   return (int)hipGetLastError();
 }

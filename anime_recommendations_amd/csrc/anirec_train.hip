@@ -25,10 +25,12 @@
 //         double-buffered by step parity so bwd(t+1) never overwrites what rest(t) still reads.
 //
 // All kernels read the step index from device memory so one captured hipGraph replays for every step:
-// fwd/head(t) from anirec_state::step_fwd (bumped by the finish of step t-1), bwd/hot(t) from the word
-// head(t) publishes (TrainWs::sel), rest(t) from anirec_state::step_bwd (set by the finish of step t,
-// which hot(t) contains).  Each word has exactly one writer that runs strictly before its readers.
+// fwd/head(t) from anirec_state::step_fwd (bumped by the finish of step t-1), bwd/finish/hot(t) from the word
+// head(t) publishes (TrainWs::sel[0]), rest(t) from the word hot(t) publishes (sel[1]).  Each word has exactly
+// one writer that runs strictly before its readers.
 #include <hip/hip_runtime.h>
+
+#include <stdlib.h>
 
 #include <new>
 
@@ -619,7 +621,7 @@ struct BwdArgs {
   int32_t *rowmap;
 };
 
-__global__ __launch_bounds__(256) void k_bwd(BwdArgs a) {
+__global__ __launch_bounds__(256, 7) void k_bwd(BwdArgs a) {
   __shared__ float scratch[2 * 16];
   const int par = a.sel[0] & 1;
   const StepPub pub = a.pub[par];
@@ -697,19 +699,20 @@ __global__ __launch_bounds__(256) void k_bwd(BwdArgs a) {
     acc.z += cq * r0[q].z;
     acc.w += cq * r0[q].w;
   }
-  for (int j = 4; j < len; j += 4) {
-    int oj[4];
-    float cj[4];
-    float4 r[4];
+  for (int j = 4; j < len; j += 8) {  // eight rows in flight (same order of the adds: bit-reproducible)
+    int oj[8];
+    float cj[8];
+    float4 r[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      oj[q] = __shfl(o, j + q, 32);
-      cj[q] = __shfl(cf, j + q, 32);
+    for (int q = 0; q < 8; ++q) {
+      const int src = min(j + q, 31);  // lanes >= len hold weight 0 and a valid row; past lane 31: weight 0
+      oj[q] = __shfl(o, src, 32);
+      cj[q] = j + q < 32 ? __shfl(cf, src, 32) : 0.f;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = W4[(size_t)oj[q] * kRowVec + l];
+    for (int q = 0; q < 8; ++q) r[q] = W4[(size_t)oj[q] * kRowVec + l];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 8; ++q) {
       acc.x += cj[q] * r[q].x;
       acc.y += cj[q] * r[q].y;
       acc.z += cj[q] * r[q].z;
@@ -723,6 +726,34 @@ __global__ __launch_bounds__(256) void k_bwd(BwdArgs a) {
   if (l == 0) {
     a.S[pc] = ssum;
     if (rec.w > 0) a.rowmap[(size_t)par * a.rows + rec.x] = ((gc << 10) | (rec.w - 1)) + 1;
+  }
+}
+
+// g += P[c], s += S[c] for c = c0 .. c1-1 IN THAT ORDER (the sums are bit-reproducible), the loads issued kB
+// at a time: a popular anime row has ~30 chunks per batch, and one dependent L2 round trip per chunk was the
+// critical path of the hot launch
+template <int kB = 8>
+__device__ __forceinline__ void add_chunks(const float4 *P4, const float *S, int c0, int c1, int l, float4 &g,
+                                           float &s) {
+  for (int c = c0; c < c1; c += kB) {
+    float4 p[kB];
+    float sv[kB];
+#pragma unroll
+    for (int k = 0; k < kB; ++k) {
+      const int cc = min(c + k, c1 - 1);
+      p[k] = P4[(size_t)cc * kRowVec + l];
+      sv[k] = S[cc];
+    }
+#pragma unroll
+    for (int k = 0; k < kB; ++k) {
+      if (c + k < c1) {
+        g.x += p[k].x;
+        g.y += p[k].y;
+        g.z += p[k].z;
+        g.w += p[k].w;
+        s += sv[k];
+      }
+    }
   }
 }
 
@@ -752,14 +783,7 @@ __global__ __launch_bounds__(256) void k_densify(DensifyArgs a) {
     float s = 0.f;
     if (rm) {
       const int first = (rm - 1) >> 10, nch = ((rm - 1) & 1023) + 1;
-      for (int c = first; c < first + nch; ++c) {
-        const float4 p = P4[(size_t)c * kRowVec + l];
-        g.x += p.x;
-        g.y += p.y;
-        g.z += p.z;
-        g.w += p.w;
-        s += S[c];
-      }
+      add_chunks(P4, S, first, first + nch, l, g, s);
       if (l == 0) rowmap[gr] = 0;
     }
     reinterpret_cast<float4 *>(a.dense)[(size_t)r * kRowVec + l] = g;
@@ -780,7 +804,7 @@ struct AdamArgs {
   int rows;         // all table rows (stride of the two row maps)
   int capC;
   int parts;        // bit0: write the user-row L2 partials, bit1: the anime-row ones, bit2: finish the step
-  int step_src;     // 0: step = *sel (launches that run before the step's finish); 1: state->step_bwd (rest)
+  int step_src;     // 0: step = sel[0] (published by head: bwd, hot, finish, full adam); 1: sel[1] (rest: published by hot)
   int dense_lo, dense_rows;  // dense != nullptr: rows >= dense_lo take their (already reduced) gradient from it
   int rest_blocks, hot_blocks;  // grids whose L2 partials the finish adds up
   int32_t *rowmap;  // [2][rows]
@@ -844,7 +868,7 @@ __device__ __forceinline__ void row_issue(const AdamArgs &a, int par, int r, int
 
 // returns sum(W_new^2) of this lane's four elements (0 for a skipped row); `mark` is what the row map word of a
 // touched row becomes: 0 (consumed) or -1 (hot launch: "already updated", cleared by the rest launch)
-template <bool kNT>
+template <bool kNT, int kB = 8>
 __device__ __forceinline__ float row_finish(const AdamArgs &a, int par, int r, int l, float alpha, RowLoad &x,
                                             int mark) {
   int32_t *rmw = a.rowmap + (size_t)par * a.rows + r;
@@ -859,14 +883,7 @@ __device__ __forceinline__ float row_finish(const AdamArgs &a, int par, int r, i
     const float4 *P4 = reinterpret_cast<const float4 *>(a.P) + (size_t)par * 2 * a.capC * kRowVec;
     const float *S = a.S + (size_t)par * 2 * a.capC;
     const int first = (x.rm - 1) >> 10, nch = ((x.rm - 1) & 1023) + 1;
-    for (int c = first + 1; c < first + nch; ++c) {  // rows with > ANIREC_CHUNK contributions
-      const float4 p = P4[(size_t)c * kRowVec + l];
-      g.x += p.x;
-      g.y += p.y;
-      g.z += p.z;
-      g.w += p.w;
-      s += S[c];
-    }
+    if (nch > 1) add_chunks<kB>(P4, S, first + 1, first + nch, l, g, s);  // rows with > ANIREC_CHUNK contributions
   }
   if ((x.rm || mark) && l == 0) *rmw = mark;
   float4 w = x.w, m = x.m, v = x.v;
@@ -913,6 +930,38 @@ __device__ __forceinline__ void block_sq_partials(float sq, float sqa, float *sc
 __device__ __forceinline__ void finish_step(const AdamArgs &a, int par, float *scratch) {
   const StepPub pub = a.pub[par];
   const float *hpart = a.hpart + par * a.hpart_stride;
+  anirec_state *st = a.state;
+  // every load of this function is issued before the first use: it is a chain of L2 round trips otherwise
+  // (the L2 partials beyond a launch's grid are zero: whole arrays are read, 16 B per lane)
+  const int pp = par ^ 1;
+  constexpr int kRv = ANIREC_ADAM_BLOCKS / (4 * 256);  // float4 per thread and table
+  constexpr int kHv = (kHotBlocksMax / 4 + 255) / 256;
+  const float4 *ru = reinterpret_cast<const float4 *>(a.regpart + (size_t)(pp * 2 + 0) * ANIREC_ADAM_BLOCKS);
+  const float4 *ra = reinterpret_cast<const float4 *>(a.regpart + (size_t)(pp * 2 + 1) * ANIREC_ADAM_BLOCKS);
+  const float4 *hu = reinterpret_cast<const float4 *>(a.reghot + (size_t)(pp * 2 + 0) * kHotBlocksMax);
+  const float4 *ha = reinterpret_cast<const float4 *>(a.reghot + (size_t)(pp * 2 + 1) * kHotBlocksMax);
+  float4 vu[kRv], va[kRv], wu[kHv], wa[kHv];
+#pragma unroll
+  for (int k = 0; k < kRv; ++k) {
+    vu[k] = ru[threadIdx.x + 256 * k];
+    va[k] = ra[threadIdx.x + 256 * k];
+  }
+#pragma unroll
+  for (int k = 0; k < kHv; ++k) {
+    const int i4 = threadIdx.x + 256 * k;
+    const bool in = i4 < kHotBlocksMax / 4;
+    wu[k] = in ? hu[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    wa[k] = in ? ha[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float am[4], av[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    am[k] = st->adam_m[k];
+    av[k] = st->adam_v[k];
+  }
+  const float mmean = st->mov_mean, mvar = st->mov_var;
+  const double o_loss = st->loss_wsum, o_bce = st->bce_wsum, o_ru = st->reg_user_wsum, o_ra = st->reg_anime_wsum,
+               o_se = st->se_sum, o_n = st->n_seen;
   float h[kHeadCols];
 #pragma unroll
   for (int k = 0; k < kHeadCols; ++k) h[k] = 0.f;
@@ -920,22 +969,20 @@ __device__ __forceinline__ void finish_step(const AdamArgs &a, int par, float *s
 #pragma unroll
     for (int k = 0; k < kHeadCols; ++k) h[k] += hpart[(size_t)blk * kHeadCols + k];
   }
-  const int pp = par ^ 1;
   float q[2] = {0.f, 0.f};
-  const float *ru = a.regpart + (size_t)(pp * 2 + 0) * ANIREC_ADAM_BLOCKS, *ra = ru + ANIREC_ADAM_BLOCKS;
-  for (int i = threadIdx.x; i < a.rest_blocks; i += 256) {
-    q[0] += ru[i];
-    q[1] += ra[i];
+#pragma unroll
+  for (int k = 0; k < kRv; ++k) {
+    q[0] += (vu[k].x + vu[k].y) + (vu[k].z + vu[k].w);
+    q[1] += (va[k].x + va[k].y) + (va[k].z + va[k].w);
   }
-  const float *hu = a.reghot + (size_t)(pp * 2 + 0) * kHotBlocksMax, *ha = hu + kHotBlocksMax;
-  for (int i = threadIdx.x; i < a.hot_blocks; i += 256) {
-    q[0] += hu[i];
-    q[1] += ha[i];
+#pragma unroll
+  for (int k = 0; k < kHv; ++k) {
+    q[0] += (wu[k].x + wu[k].y) + (wu[k].z + wu[k].w);
+    q[1] += (wa[k].x + wa[k].y) + (wa[k].z + wa[k].w);
   }
   block_sum<kHeadCols>(h, scratch);
   block_sum<2>(q, scratch);
   if (threadIdx.x == 0) {
-    anirec_state *st = a.state;
     const double n = (double)pub.n_total;
     const double S1 = h[0], S2 = h[1], L = h[2], SE = h[3];
     const double Sdc = h[4], Sc = h[5], Szc = h[6], Sz = h[7];
@@ -948,7 +995,7 @@ __device__ __forceinline__ void finish_step(const AdamArgs &a, int par, float *s
     const float g4[4] = {dW, dB, (float)S2, (float)S1};  // d w, d b, d gamma, d beta
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      float mm = st->adam_m[k], vv = st->adam_v[k];
+      float mm = am[k], vv = av[k];
       adam_elem(p4[k], mm, vv, g4[k], pub.alpha);
       st->adam_m[k] = mm;
       st->adam_v[k] = vv;
@@ -957,7 +1004,6 @@ __device__ __forceinline__ void finish_step(const AdamArgs &a, int par, float *s
     st->b = p4[1];
     st->gamma = p4[2];
     st->beta = p4[3];
-    const float mmean = st->mov_mean, mvar = st->mov_var;
     st->mov_mean = mmean - (mmean - pub.mu) * kBnDecay;
     st->mov_var = mvar - (mvar - pub.var) * kBnDecay;
     const float reg_u = q[0], reg_a = q[1];
@@ -970,12 +1016,12 @@ __device__ __forceinline__ void finish_step(const AdamArgs &a, int par, float *s
     const float loss = (float)(L / n) + pub.l2 * reg;
     st->last_loss = loss;
     st->last_mse = (float)(SE / n);
-    st->loss_wsum += (double)loss * n;
-    st->bce_wsum += L;
-    st->reg_user_wsum += (double)reg_u * n;
-    st->reg_anime_wsum += (double)reg_a * n;
-    st->se_sum += SE;
-    st->n_seen += n;
+    st->loss_wsum = o_loss + (double)loss * n;
+    st->bce_wsum = o_bce + L;
+    st->reg_user_wsum = o_ru + (double)reg_u * n;
+    st->reg_anime_wsum = o_ra + (double)reg_a * n;
+    st->se_sum = o_se + SE;
+    st->n_seen = o_n + n;
     st->step_bwd = pub.step;
     st->step_fwd = pub.step + 1;
   }
@@ -989,7 +1035,7 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
   __shared__ float scratch[kHeadCols * 16];
   const int l = threadIdx.x & 31;
   const int nhw = gridDim.x * 8;
-  const int step = a.step_src ? a.state->step_bwd : a.sel[0];
+  const int step = a.sel[a.step_src];
   const int par = step & 1;
   const float alpha = a.pub[par].alpha;
   const int32_t *rowmap = a.rowmap + (size_t)par * a.rows;
@@ -1037,33 +1083,60 @@ struct HotArgs {
   int cap, arena_steps, n_steps_total;
 };
 
-__global__ __launch_bounds__(256) void k_adam_hot(HotArgs h) {
+__global__ __launch_bounds__(256, 8) void k_adam_hot(HotArgs h) {  // one row per half-wave: lives on occupancy
   __shared__ float scratch[kHeadCols * 16];
   const AdamArgs &a = h.a;
-  const int l = threadIdx.x & 31;
+  // round trip 1: the step index and BOTH parities' step size together
   const int step = a.sel[0];
+  const float alpha0 = a.pub[0].alpha, alpha1 = a.pub[1].alpha;
   const int par = step & 1;
-  const float alpha = a.pub[par].alpha;
+  const float alpha = par ? alpha1 : alpha0;
+  const int l = threadIdx.x & 31;
   const int hw = blockIdx.x * 8 + (threadIdx.x >> 5);
   const int T = hw >= a.capC ? 1 : 0;
   const int c = hw - T * a.capC;
   float sq = 0.f, sqa = 0.f;
-  if (step + 1 < h.n_steps_total && T < 2) {
+  if (step + 1 < h.n_steps_total && hw < 2 * a.capC) {
     Slot sl = slot_of(h.arena, h.slot_bytes, h.cap, a.capC, (step + 1) % h.arena_steps);
-    if (c < min(sl.nchunks[T], a.capC)) {
-      const int4 rec = sl.chunks[T * a.capC + c];
-      const int r = rec.x;
-      if (rec.w > 0 && r >= 0 && r < a.rows) {
-        RowLoad x;
-        row_issue<false>(a, par, r, l, a.rowmap[(size_t)par * a.rows + r], x);
-        const float q = row_finish<false>(a, par, r, l, alpha, x, -1);
+    // round trip 2: the chunk record and the chunk count together (the record is read unconditionally: in bounds)
+    const int nch = sl.nchunks[T];
+    const int4 rec = sl.chunks[T * a.capC + c];
+    const int r = rec.x;
+    if (c < min(nch, a.capC) && rec.w > 0 && r >= 0 && r < a.rows) {
+      // round trip 3: the row map word and the three row streams together; 4 (touched rows): the chunk partial
+      RowLoad x;
+      const size_t e = (size_t)r * kRowVec + l;
+      const int rm = a.rowmap[(size_t)par * a.rows + r];
+      x.w = reinterpret_cast<const float4 *>(a.W)[e];
+      x.m = reinterpret_cast<const float4 *>(a.M)[e];
+      x.v = reinterpret_cast<const float4 *>(a.V)[e];
+      x.rm = rm > 0 ? rm : 0;
+      x.p0 = make_float4(0.f, 0.f, 0.f, 0.f);
+      x.s0 = 0.f;
+      if (rm > 0) {
+        const size_t first = (size_t)par * 2 * a.capC + ((rm - 1) >> 10);
+        x.p0 = reinterpret_cast<const float4 *>(a.P)[first * kRowVec + l];
+        x.s0 = a.S[first];
+      }
+      if (rm >= 0) {  // (< 0: a stale slot listed the row twice — already updated)
+        const float q = row_finish<false, 4>(a, par, r, l, alpha, x, -1);
         if (r < a.n_user_rows) sq = q; else sqa = q;
       }
     }
   }
   float *rh = a.reghot + (size_t)(par * 2) * kHotBlocksMax;
   block_sq_partials(sq, sqa, scratch, rh + blockIdx.x, rh + kHotBlocksMax + blockIdx.x);
-  if (blockIdx.x == 0) finish_step(a, par, scratch);
+  // the rest launch of this step runs right behind this one on the same stream, possibly beside head(t+1) which
+  // moves sel[0] on: it takes its step index from a word only this launch writes
+  if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<int32_t *>(a.sel)[1] = step;
+}
+
+// the finish of a one-GPU step as a launch of its own (one workgroup): it needs the head partials of step t and
+// the L2 partials of step t-1 only, so the captured graph runs it BESIDE the hot launch (whose registers it would
+// otherwise inflate: the hot launch lives on occupancy)
+__global__ __launch_bounds__(256) void k_finish(AdamArgs a) {
+  __shared__ float scratch[kHeadCols * 16];
+  finish_step(a, a.sel[0] & 1, scratch);
 }
 
 // sum(W^2) partials of the CURRENT weights into both parities (after (re)loading weights, before validation):
@@ -1368,6 +1441,12 @@ static int launch_adam_hot(const anirec_train_desc *d, const TrainWs &w, hipStre
   return (int)hipGetLastError();
 }
 
+static int launch_finish(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
+  const AdamArgs a = adam_args(d, w);
+  hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+
 static int launch_adam_rest(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
   AdamArgs a = adam_args(d, w);
   a.parts = 3;
@@ -1403,7 +1482,8 @@ static int launch_adam_full(const anirec_train_desc *d, const TrainWs &w, hipStr
 
 static int launch_adam(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
   if (d->dense_mode) return launch_adam_full(d, w, s, 0);
-  int e = launch_adam_hot(d, w, s);
+  int e = launch_finish(d, w, s);
+  if (!e) e = launch_adam_hot(d, w, s);
   return e ? e : launch_adam_rest(d, w, s);
 }
 
@@ -1514,7 +1594,9 @@ int anirec_train_adam_part(const anirec_train_desc *d, int32_t which, void *stre
     case 3:  // one GPU: hot rows + finish
     case 4:  // one GPU: the rest
       if (d->dense_mode != 0) return ANIREC_EINVAL;
-      return which == 3 ? launch_adam_hot(d, w, s) : launch_adam_rest(d, w, s);
+      if (which == 4) return launch_adam_rest(d, w, s);
+      if (int e = launch_finish(d, w, s)) return e;
+      return launch_adam_hot(d, w, s);
     default:
       return ANIREC_EINVAL;
   }
@@ -1593,8 +1675,8 @@ struct anirec_trainer {
   TrainWs ws;
   hipGraphExec_t exec;
   int graph_steps;
-  hipStream_t side;         // second graph branch: fwd/head/bwd(t+1) beside rest(t)
-  hipEvent_t fork, join;
+  hipStream_t side;         // second graph branch: finish(t), then fwd/head/bwd(t+1) beside rest(t)
+  hipEvent_t fork, fork2, join;
 };
 
 int anirec_trainer_create(const anirec_train_desc *d, anirec_trainer **out) {
@@ -1609,9 +1691,10 @@ int anirec_trainer_create(const anirec_train_desc *d, anirec_trainer **out) {
   t->exec = nullptr;
   t->graph_steps = 0;
   t->side = nullptr;
-  t->fork = t->join = nullptr;
+  t->fork = t->fork2 = t->join = nullptr;
   if (hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&t->fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&t->fork2, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&t->join, hipEventDisableTiming) != hipSuccess) {
     anirec_trainer_destroy(t);
     return ANIREC_ENODEVICE;
@@ -1624,6 +1707,7 @@ int anirec_trainer_destroy(anirec_trainer *t) {
   if (!t) return ANIREC_EINVAL;
   if (t->exec) (void)hipGraphExecDestroy(t->exec);
   if (t->fork) (void)hipEventDestroy(t->fork);
+  if (t->fork2) (void)hipEventDestroy(t->fork2);
   if (t->join) (void)hipEventDestroy(t->join);
   if (t->side) (void)hipStreamDestroy(t->side);
   delete t;
@@ -1640,26 +1724,32 @@ static int front_of_step(anirec_trainer *t, hipStream_t s) {
 static int one_step(anirec_trainer *t, hipStream_t s) {
   int e;
   if ((e = front_of_step(t, s))) return e;
+  if ((e = launch_finish(&t->d, t->ws, s))) return e;
   if ((e = launch_adam_hot(&t->d, t->ws, s))) return e;
   return launch_adam_rest(&t->d, t->ws, s);
 }
 
-// G steps as a two-branch chain: front(0) hot(0) { rest(0) || front(1) } hot(1) { rest(1) || front(2) } ...
-// front(t+1) only reads rows that hot(t) has updated and writes the other parity's scratch, so it runs beside
-// the long rest(t) stream; hot(t+1) needs both.
+// G steps as a two-branch chain (s = main stream, side = second branch):
+//     front(0)  { hot(0) || finish(0) }  { rest(0) || front(1) }  { hot(1) || finish(1) }  { rest(1) || front(2) } ...
+// front(t+1) = fwd/head/bwd of step t+1 only reads rows that hot(t) has updated, the scalars finish(t) has
+// written, and writes the other parity's scratch, so it runs beside the long rest(t) stream; hot(t+1) needs
+// both rest(t) (every row it touches must have had its step-t update) and front(t+1).
 static int overlapped_steps(anirec_trainer *t, int G, hipStream_t s) {
   int e = front_of_step(t, s);
   for (int i = 0; i < G && !e; ++i) {
-    if ((e = launch_adam_hot(&t->d, t->ws, s))) break;
+    ANIREC_HIP_CHECK(hipEventRecord(t->fork, s));            // bwd(i) [and rest(i-1)] done
+    ANIREC_HIP_CHECK(hipStreamWaitEvent(t->side, t->fork, 0));
+    if ((e = launch_finish(&t->d, t->ws, t->side))) break;    // side: finish(i)
+    if ((e = launch_adam_hot(&t->d, t->ws, s))) break;        // main: hot(i)
     const bool more = i + 1 < G;
     if (more) {
-      ANIREC_HIP_CHECK(hipEventRecord(t->fork, s));
-      ANIREC_HIP_CHECK(hipStreamWaitEvent(t->side, t->fork, 0));
-      if ((e = front_of_step(t, t->side))) break;
-      ANIREC_HIP_CHECK(hipEventRecord(t->join, t->side));
+      ANIREC_HIP_CHECK(hipEventRecord(t->fork2, s));          // hot(i) done
+      ANIREC_HIP_CHECK(hipStreamWaitEvent(t->side, t->fork2, 0));
+      if ((e = front_of_step(t, t->side))) break;             // side: front(i+1), after finish(i) and hot(i)
     }
-    if ((e = launch_adam_rest(&t->d, t->ws, s))) break;
-    if (more) ANIREC_HIP_CHECK(hipStreamWaitEvent(s, t->join, 0));
+    ANIREC_HIP_CHECK(hipEventRecord(t->join, t->side));
+    if ((e = launch_adam_rest(&t->d, t->ws, s))) break;       // main: rest(i)
+    ANIREC_HIP_CHECK(hipStreamWaitEvent(s, t->join, 0));      // both branches meet before hot(i+1) / the graph's end
   }
   return e;
 }
@@ -1678,6 +1768,21 @@ int anirec_trainer_run(anirec_trainer *t, int32_t first_step, int32_t n_steps, i
   int G = t->d.arena_steps / 2;
   if (G > 32) G = 32;
   int done = 0;
+  // ANIREC_TRAIN_MODE (A/B on one box): "graph_serial" = the captured graph without the second branch,
+  // "eager_overlap" = the two-branch chain launched eagerly on two streams (no graph)
+  const char *tm = getenv("ANIREC_TRAIN_MODE");
+  const bool serial_graph = tm && tm[0] == 'g' && tm[6] == 's';
+  if (tm && tm[0] == 'e' && use_graph && s != nullptr) {
+    while (done < n_steps) {
+      int blk = n_steps - done;
+      if (blk > t->d.arena_steps - 1) blk = t->d.arena_steps - 1;
+      int e = launch_prep(&t->d, t->ws, first_step + done, blk + 1, false, s);
+      if (!e) e = overlapped_steps(t, blk, s);
+      if (e) return e;
+      done += blk;
+    }
+    return ANIREC_OK;
+  }
   const bool graph = use_graph && s != nullptr && G >= 4 && n_steps >= G;
   if (graph) {
     if (!t->exec || t->graph_steps != G) {
@@ -1687,7 +1792,8 @@ int anirec_trainer_run(anirec_trainer *t, int32_t first_step, int32_t n_steps, i
       if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess)
         return ANIREC_ECAPTURE;
       int e = launch_prep(&t->d, t->ws, G, G, true, s);  // steps cursor+G .. cursor+2G
-      if (!e) e = overlapped_steps(t, G, s);
+      if (!e && !serial_graph) e = overlapped_steps(t, G, s);
+      for (int i = 0; serial_graph && i < G && !e; ++i) e = one_step(t, s);
       hipError_t ce = hipStreamEndCapture(s, &g);
       if (e || ce != hipSuccess || !g) {
         if (g) (void)hipGraphDestroy(g);

@@ -83,7 +83,7 @@ def test_s7m_shape_graph_overlap_is_bitwise_the_serial_run_and_untouched_rows_ar
     # anime rows no batch touched only see g = 2*l2*W: bit for bit the oracle's Adam
     n_u = 15_000
     untouched = np.setdiff1d(np.arange(A0.shape[0]), np.unique(ai))[:3000]
-    assert len(untouched) > 100
+    assert len(untouched) > 20
     w = A0[untouched].copy()
     m = np.zeros_like(w)
     v = np.zeros_like(w)
