@@ -17,7 +17,6 @@ DIM = 128
 MAX_BATCH = 16384
 CHUNK = 32
 ADAM_BLOCKS = 8192
-HOT_BLOCKS_MAX = 4352      # kHotBlocksMax of csrc/anirec_train.hip (workspace layout mirror, tests only)
 MAX_TOPK = 128
 MAX_SEG = 16
 ABI_VERSION = 2
@@ -90,6 +89,7 @@ PROTOTYPES = {
     "anirec_train_bwd": (C.c_int, [_DP, _vp]),
     "anirec_train_adam": (C.c_int, [_DP, _vp]),
     "anirec_train_adam_part": (C.c_int, [_DP, _i32, _vp]),
+    "anirec_train_stage_time": (C.c_int, [_DP, _i32, _i32, C.POINTER(C.c_float), _vp]),
     "anirec_dist_stepper_create": (C.c_int, [_DP, C.POINTER(_vp)]),
     "anirec_dist_stepper_destroy": (C.c_int, [_vp]),
     "anirec_dist_step_mid": (C.c_int, [_vp, _vp]),

@@ -15,19 +15,22 @@
 //   adam  half-wave per table row, dense: g = chunk sums - s*W + 2*l2*W, Keras-2.12 Adam,
 //         emits sum(W_new^2) partials for the L2 loss term.  HBM-bound: 24 B/element
 //         (+512 B per touched row) instead of 28 because the dense gradient never exists.
-//         On one GPU the update of step t is cut in two launches so that the small kernels of step t+1
-//         leave the critical path:
-//           hot(t)   the rows batch t+1 touches (the first-chunk records of its prepared slot) + the step
-//                    finish (Adam on the 4 head scalars, moving stats, History metrics, step cursor);
-//           rest(t)  every other row — the long HBM stream — beside which fwd/head/bwd(t+1) run on a
-//                    second branch of the captured graph (they only read rows hot(t) has finished).
+//         Workgroup 0 finishes the step (Adam on the 4 head scalars, moving stats, History metrics, step cursor).
 //         Per-step scratch (chunk partials, row map, head partials, step constants, L2 partials) is
-//         double-buffered by step parity so bwd(t+1) never overwrites what rest(t) still reads.
+//         double-buffered by step parity: the multi-GPU step forks the user-row Adam onto a side stream beside the
+//         densify pass + collective, and nothing of step t+1 can then overwrite what step t still reads.
 //
 // All kernels read the step index from device memory so one captured hipGraph replays for every step:
-// fwd/head(t) from anirec_state::step_fwd (bumped by the finish of step t-1), bwd/finish/hot(t) from the word
-// head(t) publishes (TrainWs::sel[0]), rest(t) from the word hot(t) publishes (sel[1]).  Each word has exactly
-// one writer that runs strictly before its readers.
+// fwd/head(t) from anirec_state::step_fwd (bumped by the finish of step t-1), bwd/densify/adam(t) from the word
+// head(t) publishes (TrainWs::sel).  Each word has exactly one writer that runs strictly before its readers.
+//
+// Tried on the GPU and dropped (round 2): cutting the dense update in two launches — hot(t): the rows batch t+1
+// touches, rest(t): everything else — so that fwd/head/bwd(t+1) could run beside the long rest(t) stream.  Bit-
+// identical results, but no faster: as a second hipGraph branch or on a second stream every cross-branch edge
+// costs ~12 us on this stack (rocprofv3 trace: 12-14 us gaps at each fork / join), more than the 29 us of small
+// kernels it hides once the extra hot launch (13 us) is paid; fused INTO the rest launch (256-1024 workgroups
+// running fwd -> barrier -> head -> barrier -> bwd beside the stream) the latency-bound chain crawls behind the
+// bandwidth-saturating stream (270-400 us per step against 232).
 #include <hip/hip_runtime.h>
 
 #include <stdlib.h>
@@ -49,7 +52,6 @@ struct StepPub {
   float l2, pad0, pad1, pad2;
 };
 
-constexpr int kHotBlocksMax = 4352;  // >= ceil(2 * chunk_capacity(ANIREC_MAX_BATCH) / 8), multiple of 256
 
 struct TrainWs {
   int cap, capC, arena_steps;
@@ -59,9 +61,8 @@ struct TrainWs {
   float *hpart;                 // [2][ANIREC_MAX_SEG * ceil(cap/256)][8] head partial sums
   size_t hpart_stride;          // floats per parity
   StepPub *pub;                 // [2] step constants published by head workgroup 0
-  int32_t *sel;                 // step index of the last head launch (read by bwd / densify / hot / full adam)
-  float *regpart;               // [2][2][ANIREC_ADAM_BLOCKS]: user-row / anime-row sum(W^2) partials of rest / full adam
-  float *reghot;                // [2][2][kHotBlocksMax]: the same of the hot launch
+  int32_t *sel;                 // step index of the last head launch (read by bwd / densify / adam)
+  float *regpart;               // [2][2][ANIREC_ADAM_BLOCKS]: user-row / anime-row sum(W^2) partials
   float *P;                     // [2][2*capC][128] chunk partial rows
   float *S;                     // [2][2*capC]      chunk self-coefficient sums
   // arena slot s: nchunks[2] (4 ints), sidx[2][cap], oth[2][cap], chunks[2][capC] (int4)
@@ -99,7 +100,6 @@ __host__ inline TrainWs carve(void *base, int cap, int arena_steps) {
   w.pub = (StepPub *)take(sizeof(StepPub) * 2);
   w.sel = (int32_t *)take(sizeof(int32_t) * 4);
   w.regpart = (float *)take(sizeof(float) * 2 * 2 * ANIREC_ADAM_BLOCKS);
-  w.reghot = (float *)take(sizeof(float) * 2 * 2 * kHotBlocksMax);
   w.P = (float *)take(sizeof(float) * 2 * 2 * (size_t)w.capC * kDim);
   w.S = (float *)take(sizeof(float) * 2 * 2 * (size_t)w.capC);
   w.slot_bytes = align_up(16) + 2 * align_up(sizeof(int32_t) * 2 * (size_t)cap) +
@@ -376,11 +376,16 @@ __device__ __forceinline__ float cos_from_dots(float su, float sa, float dd) {
   return dd * ru * ra;
 }
 
-__global__ __launch_bounds__(256) void k_fwd(FwdArgs a) {
-  const anirec_step sc = a.sched[a.state->step_fwd];
+// the packet count word travels through an all-gather on the multi-GPU path: read it with an agent-scope load
+__device__ __forceinline__ int ld_i32(const int32_t *p) {
+  return __hip_atomic_load(const_cast<int32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the forward pass of one workgroup: 8 ratings, a half-wave each
+__device__ __forceinline__ void fwd_block(const FwdArgs &a, const anirec_step sc, int vblk) {
   const int nb = min(sc.count, a.cap);
-  const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.pk_count[0] = nb;
+  const int i = vblk * 8 + (threadIdx.x >> 5);
+  if (vblk == 0 && threadIdx.x == 0) a.pk_count[0] = nb;
   if (i >= nb) return;
   const int l32 = threadIdx.x & 31;
   const int g = sc.start + i;
@@ -394,6 +399,10 @@ __global__ __launch_bounds__(256) void k_fwd(FwdArgs a) {
     a.su[i] = su;
     a.sa[i] = sa;
   }
+}
+
+__global__ __launch_bounds__(256) void k_fwd(FwdArgs a) {
+  fwd_block(a, a.sched[a.state->step_fwd], blockIdx.x);
 }
 
 // Multi-GPU only: (mean, M2) of this rank's z = w*c + b values, two-pass, written next to the
@@ -447,7 +456,7 @@ __device__ __forceinline__ float bce_logits(float y, float t) {
 }
 
 __device__ __forceinline__ int packet_count(const float *pk, int cap) {
-  return min(reinterpret_cast<const int32_t *>(pk + 2 * (size_t)packet_cap(cap))[0], cap);
+  return min(ld_i32(reinterpret_cast<const int32_t *>(pk + 2 * (size_t)packet_cap(cap))), cap);
 }
 
 // A packet's c values for the batch statistics: every 16-B load of the thread is issued before
@@ -455,6 +464,10 @@ __device__ __forceinline__ int packet_count(const float *pk, int cap) {
 // the packet's count word, so state, counts and values arrive in ONE memory round trip.
 constexpr int kHeadVec = ANIREC_MAX_BATCH / (4 * kHeadThreads);  // 16 float4 per thread at most
 
+// A packet's c values for the batch statistics: every 16-B load of the thread is issued before the first use (a
+// scalar strided loop serialises ~40 L2 round trips) and does not depend on the packet's count word, so state,
+// counts and values arrive in ONE memory round trip; they stay in registers for both passes (re-reading them
+// from L2 for the second pass measured 12.1 us per launch against 8.8 us).
 struct SegVals {
   float4 v[kHeadVec];
 };
@@ -486,14 +499,19 @@ __device__ __forceinline__ float seg_stat(const SegVals &x, int cnt, float w, fl
   return acc;
 }
 
-__global__ __launch_bounds__(kHeadThreads) void k_head(HeadArgs a) {
-  __shared__ float scratch[kHeadCols * 16];
+// the step index and the four head scalars a head workgroup works with
+struct HeadIn {
+  int step;
+  float w, b, gamma, beta;
+};
+
+// workgroup vblk of nvb: the batch statistics (recomputed per workgroup) + 256 ratings
+__device__ __forceinline__ void head_block(const HeadArgs &a, const HeadIn in, int vblk, int nvb, float *scratch) {
   const int tid = threadIdx.x;
-  const anirec_state *st = a.state;
   const int pcap = packet_cap(a.cap);
   const int bps = (a.cap + kHeadThreads - 1) / kHeadThreads;  // blocks per segment
-  const int seg = blockIdx.x / bps;
-  const int i = (blockIdx.x % bps) * kHeadThreads + tid;
+  const int seg = vblk / bps;
+  const int i = (vblk % bps) * kHeadThreads + tid;
 
   // ---- issue every independent load first --------------------------------------------
   SegVals x0;
@@ -501,8 +519,8 @@ __global__ __launch_bounds__(kHeadThreads) void k_head(HeadArgs a) {
   const float *mypk = a.packets + a.packet_floats * seg;
   const float my_c = i < a.cap ? mypk[i] : 0.f;
   const float my_t = i < a.cap ? mypk[pcap + i] : 0.f;
-  const int step = st->step_fwd;
-  const float w = st->w, b = st->b, gamma = st->gamma, beta = st->beta;
+  const int step = in.step;
+  const float w = in.w, b = in.b, gamma = in.gamma, beta = in.beta;
   int cnts[ANIREC_MAX_SEG];
   int n_total = 0;
 #pragma unroll
@@ -577,14 +595,14 @@ __global__ __launch_bounds__(kHeadThreads) void k_head(HeadArgs a) {
   }
   block_sum<kHeadCols>(r, scratch);
   const int par = step & 1;
-  if (tid < kHeadCols) a.hpart[par * a.hpart_stride + (size_t)blockIdx.x * kHeadCols + tid] = r[tid];
+  if (tid < kHeadCols) a.hpart[par * a.hpart_stride + (size_t)vblk * kHeadCols + tid] = r[tid];
 
-  if (blockIdx.x == 0) {
+  if (vblk == 0) {
     if (tid == 0) {
       StepPub p;
       p.slot = step % a.arena_steps;
       p.n_total = n_total;
-      p.n_head_blocks = gridDim.x;
+      p.n_head_blocks = nvb;
       p.step = step;
       p.alpha = a.sched[step].alpha;
       p.mu = mu;
@@ -600,6 +618,13 @@ __global__ __launch_bounds__(kHeadThreads) void k_head(HeadArgs a) {
       a.sel[0] = step;
     }
   }
+}
+
+__global__ __launch_bounds__(kHeadThreads) void k_head(HeadArgs a) {
+  __shared__ float scratch[kHeadCols * 16];
+  const anirec_state *st = a.state;
+  const HeadIn in = {st->step_fwd, st->w, st->b, st->gamma, st->beta};
+  head_block(a, in, blockIdx.x, gridDim.x, scratch);
 }
 
 // ------------------------------------------------------------------------------------
@@ -621,53 +646,65 @@ struct BwdArgs {
   int32_t *rowmap;
 };
 
-__global__ __launch_bounds__(256, 7) void k_bwd(BwdArgs a) {
-  __shared__ float scratch[2 * 16];
-  const int par = a.sel[0] & 1;
-  const StepPub pub = a.pub[par];
-  const float *hpart = a.hpart + par * a.hpart_stride;
-  const int l = threadIdx.x & 31;
-  const int hw = blockIdx.x * 8 + (threadIdx.x >> 5);
-  const int T = hw >= a.capC ? 1 : 0;
-  const int c = hw - T * a.capC;
-  Slot sl = slot_of(a.arena, a.slot_bytes, a.cap, a.capC, pub.slot);
-  const float4 *W4 = reinterpret_cast<const float4 *>(a.W);
-
-  // Everything this half-wave will need is requested BEFORE the block reduction of the head
-  // partials (a barrier the loads cannot cross): chunk record -> sorted index + other-table row ->
-  // the rating's scalars and the first four rows.  The kernel is a chain of dependent HBM round
-  // trips at this size; this ordering removes one of them.
-  const bool active = c < sl.nchunks[T];
-  int len = 0, i = 0, o = 0;
-  int4 rec = make_int4(0, 0, 0, 0);
-  float ci = 0.f, dyi = 0.f, su = 1.f, sa = 1.f;
+// what one half-wave needs for its chunk, requested as early as possible
+struct BwdPre {
+  bool active;
+  int T, c, len, i, o;
+  int4 rec;
+  float ci, dyi, su, sa;
   float4 r0[4];
+};
+
+__device__ __forceinline__ void bwd_prefetch(const BwdArgs &a, int slot, int vblk, BwdPre &x) {
+  const int l = threadIdx.x & 31;
+  const int hw = vblk * 8 + (threadIdx.x >> 5);
+  x.T = hw >= a.capC ? 1 : 0;
+  x.c = hw - x.T * a.capC;
+  Slot sl = slot_of(a.arena, a.slot_bytes, a.cap, a.capC, slot);
+  const float4 *W4 = reinterpret_cast<const float4 *>(a.W);
+  x.active = hw < 2 * a.capC && x.c < sl.nchunks[x.T];
+  x.len = x.i = x.o = 0;
+  x.rec = make_int4(0, 0, 0, 0);
+  x.ci = x.dyi = 0.f;
+  x.su = x.sa = 1.f;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) r0[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (active) {
-    rec = sl.chunks[T * a.capC + c];
-    len = rec.z;
+  for (int q = 0; q < 4; ++q) x.r0[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (x.active) {
+    x.rec = sl.chunks[x.T * a.capC + x.c];
+    x.len = x.rec.z;
     // lane j < len holds contribution j of the chunk; the rest replicate the last one with
     // weight 0 so every shuffle source is a valid row
-    const int pos = rec.y + min(l, len - 1);
-    i = sl.sidx[T * a.cap + pos];
-    o = sl.oth[T * a.cap + pos];
-    ci = a.pk_c[i];
-    dyi = a.dy[i];
-    su = a.su[i];
-    sa = a.sa[i];
+    const int pos = x.rec.y + min(l, x.len - 1);
+    x.i = sl.sidx[x.T * a.cap + pos];
+    x.o = sl.oth[x.T * a.cap + pos];
+    x.ci = a.pk_c[x.i];
+    x.dyi = a.dy[x.i];
+    x.su = a.su[x.i];
+    x.sa = a.sa[x.i];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) r0[q] = W4[(size_t)__shfl(o, q, 32) * kRowVec + l];
+    for (int q = 0; q < 4; ++q) x.r0[q] = W4[(size_t)__shfl(x.o, q, 32) * kRowVec + l];
   }
+}
 
-  // mean(d zhat), mean(d zhat * zhat) from the head partials (fixed order)
-  float m[2] = {0.f, 0.f};
-  for (int k = threadIdx.x; k < pub.n_head_blocks; k += 256) {
+// mean(d zhat), mean(d zhat * zhat) numerators from the head partials (fixed order); every thread gets both
+__device__ __forceinline__ void bwd_means(const float *hpart, int n_head_blocks, float *scratch, float (&m)[2]) {
+  m[0] = m[1] = 0.f;
+  for (int k = threadIdx.x; k < n_head_blocks; k += 256) {
     m[0] += hpart[(size_t)k * kHeadCols + 0];
     m[1] += hpart[(size_t)k * kHeadCols + 1];
   }
   block_sum<2>(m, scratch);
-  if (!active) return;
+}
+
+template <int kRows = 8>  // gathered rows in flight per half-wave
+__device__ __forceinline__ void bwd_chunk(const BwdArgs &a, const StepPub &pub, int par, const float (&m)[2],
+                                          const BwdPre &x) {
+  if (!x.active) return;
+  const int l = threadIdx.x & 31;
+  const int T = x.T, c = x.c, len = x.len, o = x.o;
+  const int4 rec = x.rec;
+  const float ci = x.ci, dyi = x.dyi, su = x.su, sa = x.sa;
+  const float4 *W4 = reinterpret_cast<const float4 *>(a.W);
   const float Bf = (float)pub.n_total;
   const float m1 = pub.gamma * m[0] / Bf;
   const float m2 = pub.gamma * m[1] / Bf;
@@ -694,25 +731,25 @@ __global__ __launch_bounds__(256, 7) void k_bwd(BwdArgs a) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {  // contributions 0..3 (rows already here; weight 0 past len)
     const float cq = __shfl(cf, q, 32);
-    acc.x += cq * r0[q].x;
-    acc.y += cq * r0[q].y;
-    acc.z += cq * r0[q].z;
-    acc.w += cq * r0[q].w;
+    acc.x += cq * x.r0[q].x;
+    acc.y += cq * x.r0[q].y;
+    acc.z += cq * x.r0[q].z;
+    acc.w += cq * x.r0[q].w;
   }
-  for (int j = 4; j < len; j += 8) {  // eight rows in flight (same order of the adds: bit-reproducible)
-    int oj[8];
-    float cj[8];
-    float4 r[8];
+  for (int j = 4; j < len; j += kRows) {  // kRows rows in flight (same order of the adds: bit-reproducible)
+    int oj[kRows];
+    float cj[kRows];
+    float4 r[kRows];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < kRows; ++q) {
       const int src = min(j + q, 31);  // lanes >= len hold weight 0 and a valid row; past lane 31: weight 0
       oj[q] = __shfl(o, src, 32);
       cj[q] = j + q < 32 ? __shfl(cf, src, 32) : 0.f;
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) r[q] = W4[(size_t)oj[q] * kRowVec + l];
+    for (int q = 0; q < kRows; ++q) r[q] = W4[(size_t)oj[q] * kRowVec + l];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < kRows; ++q) {
       acc.x += cj[q] * r[q].x;
       acc.y += cj[q] * r[q].y;
       acc.z += cj[q] * r[q].z;
@@ -729,9 +766,23 @@ __global__ __launch_bounds__(256, 7) void k_bwd(BwdArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256, 7) void k_bwd(BwdArgs a) {
+  __shared__ float scratch[2 * 16];
+  const int par = a.sel[0] & 1;
+  const StepPub pub = a.pub[par];
+  // Everything this half-wave will need is requested BEFORE the block reduction of the head
+  // partials (a barrier the loads cannot cross): chunk record -> sorted index + other-table row ->
+  // the rating's scalars and the first four rows.  The kernel is a chain of dependent HBM round
+  // trips at this size; this ordering removes one of them.
+  BwdPre x;
+  bwd_prefetch(a, pub.slot, blockIdx.x, x);
+  float m[2];
+  bwd_means(a.hpart + par * a.hpart_stride, pub.n_head_blocks, scratch, m);
+  bwd_chunk(a, pub, par, m, x);
+}
+
 // g += P[c], s += S[c] for c = c0 .. c1-1 IN THAT ORDER (the sums are bit-reproducible), the loads issued kB
-// at a time: a popular anime row has ~30 chunks per batch, and one dependent L2 round trip per chunk was the
-// critical path of the hot launch
+// at a time: a popular anime row has ~30 chunks per batch (one dependent L2 round trip per chunk otherwise)
 template <int kB = 8>
 __device__ __forceinline__ void add_chunks(const float4 *P4, const float *S, int c0, int c1, int l, float4 &g,
                                            float &s) {
@@ -793,8 +844,7 @@ __global__ __launch_bounds__(256) void k_densify(DensifyArgs a) {
 
 // ------------------------------------------------------------------------------------
 // adam: dense fused update of table rows; the finish of a step (scalar Adam, moving statistics,
-// History metrics, cursor) rides in workgroup 0 of the hot launch (one GPU) or of the last full
-// launch (multi-GPU)
+// History metrics, cursor) rides in workgroup 0 of the step's last adam launch
 // ------------------------------------------------------------------------------------
 struct AdamArgs {
   float *W, *M, *V;
@@ -804,9 +854,7 @@ struct AdamArgs {
   int rows;         // all table rows (stride of the two row maps)
   int capC;
   int parts;        // bit0: write the user-row L2 partials, bit1: the anime-row ones, bit2: finish the step
-  int step_src;     // 0: step = sel[0] (published by head: bwd, hot, finish, full adam); 1: sel[1] (rest: published by hot)
   int dense_lo, dense_rows;  // dense != nullptr: rows >= dense_lo take their (already reduced) gradient from it
-  int rest_blocks, hot_blocks;  // grids whose L2 partials the finish adds up
   int32_t *rowmap;  // [2][rows]
   const float *P, *S;
   const float *dense;
@@ -817,7 +865,6 @@ struct AdamArgs {
   size_t hpart_stride;
   float two_l2;
   float *regpart;  // [2][2][ANIREC_ADAM_BLOCKS]
-  float *reghot;   // [2][2][kHotBlocksMax]
 };
 
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -836,7 +883,7 @@ __device__ __forceinline__ void st_nt(float4 *p, const float4 &v) {
 struct RowLoad {
   float4 w, m, v, p0;  // p0: first chunk partial (zero if the row is untouched)
   float s0;
-  int rm;              // > 0: chunk list; 0: untouched; < 0: already updated by the hot launch (skip)
+  int rm;              // > 0: chunk list; 0: untouched
 };
 
 // issue every load of one row up front: W, M, V and — the row map word having been
@@ -847,7 +894,6 @@ __device__ __forceinline__ void row_issue(const AdamArgs &a, int par, int r, int
   x.rm = rm;
   x.p0 = make_float4(0.f, 0.f, 0.f, 0.f);
   x.s0 = 0.f;
-  if (rm < 0) return;
   const float4 *Wp = reinterpret_cast<const float4 *>(a.W) + e;
   const float4 *Mp = reinterpret_cast<const float4 *>(a.M) + e;
   const float4 *Vp = reinterpret_cast<const float4 *>(a.V) + e;
@@ -866,16 +912,10 @@ __device__ __forceinline__ void row_issue(const AdamArgs &a, int par, int r, int
   }
 }
 
-// returns sum(W_new^2) of this lane's four elements (0 for a skipped row); `mark` is what the row map word of a
-// touched row becomes: 0 (consumed) or -1 (hot launch: "already updated", cleared by the rest launch)
-template <bool kNT, int kB = 8>
-__device__ __forceinline__ float row_finish(const AdamArgs &a, int par, int r, int l, float alpha, RowLoad &x,
-                                            int mark) {
+// returns sum(W_new^2) of this lane's four elements; the row map word of a touched row is cleared
+template <bool kNT, int kB = 4>
+__device__ __forceinline__ float row_finish(const AdamArgs &a, int par, int r, int l, float alpha, RowLoad &x) {
   int32_t *rmw = a.rowmap + (size_t)par * a.rows + r;
-  if (x.rm < 0) {
-    if (l == 0) *rmw = 0;
-    return 0.f;
-  }
   const size_t e = (size_t)r * kRowVec + l;
   float4 g = x.p0;
   float s = x.s0;
@@ -885,7 +925,7 @@ __device__ __forceinline__ float row_finish(const AdamArgs &a, int par, int r, i
     const int first = (x.rm - 1) >> 10, nch = ((x.rm - 1) & 1023) + 1;
     if (nch > 1) add_chunks<kB>(P4, S, first + 1, first + nch, l, g, s);  // rows with > ANIREC_CHUNK contributions
   }
-  if ((x.rm || mark) && l == 0) *rmw = mark;
+  if (x.rm && l == 0) *rmw = 0;
   float4 w = x.w, m = x.m, v = x.v;
   g.x = grad_total(g.x, s, w.x, a.two_l2);
   g.y = grad_total(g.y, s, w.y, a.two_l2);
@@ -934,24 +974,14 @@ __device__ __forceinline__ void finish_step(const AdamArgs &a, int par, float *s
   // every load of this function is issued before the first use: it is a chain of L2 round trips otherwise
   // (the L2 partials beyond a launch's grid are zero: whole arrays are read, 16 B per lane)
   const int pp = par ^ 1;
-  constexpr int kRv = ANIREC_ADAM_BLOCKS / (4 * 256);  // float4 per thread and table
-  constexpr int kHv = (kHotBlocksMax / 4 + 255) / 256;
   const float4 *ru = reinterpret_cast<const float4 *>(a.regpart + (size_t)(pp * 2 + 0) * ANIREC_ADAM_BLOCKS);
   const float4 *ra = reinterpret_cast<const float4 *>(a.regpart + (size_t)(pp * 2 + 1) * ANIREC_ADAM_BLOCKS);
-  const float4 *hu = reinterpret_cast<const float4 *>(a.reghot + (size_t)(pp * 2 + 0) * kHotBlocksMax);
-  const float4 *ha = reinterpret_cast<const float4 *>(a.reghot + (size_t)(pp * 2 + 1) * kHotBlocksMax);
-  float4 vu[kRv], va[kRv], wu[kHv], wa[kHv];
-#pragma unroll
-  for (int k = 0; k < kRv; ++k) {
-    vu[k] = ru[threadIdx.x + 256 * k];
-    va[k] = ra[threadIdx.x + 256 * k];
-  }
-#pragma unroll
-  for (int k = 0; k < kHv; ++k) {
-    const int i4 = threadIdx.x + 256 * k;
-    const bool in = i4 < kHotBlocksMax / 4;
-    wu[k] = in ? hu[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
-    wa[k] = in ? ha[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float q[2] = {0.f, 0.f};
+#pragma unroll 2
+  for (int i4 = threadIdx.x; i4 < ANIREC_ADAM_BLOCKS / 4; i4 += 256) {
+    const float4 u = ru[i4], v = ra[i4];
+    q[0] += (u.x + u.y) + (u.z + u.w);
+    q[1] += (v.x + v.y) + (v.z + v.w);
   }
   float am[4], av[4];
 #pragma unroll
@@ -968,17 +998,6 @@ __device__ __forceinline__ void finish_step(const AdamArgs &a, int par, float *s
   for (int blk = threadIdx.x; blk < pub.n_head_blocks; blk += 256) {
 #pragma unroll
     for (int k = 0; k < kHeadCols; ++k) h[k] += hpart[(size_t)blk * kHeadCols + k];
-  }
-  float q[2] = {0.f, 0.f};
-#pragma unroll
-  for (int k = 0; k < kRv; ++k) {
-    q[0] += (vu[k].x + vu[k].y) + (vu[k].z + vu[k].w);
-    q[1] += (va[k].x + va[k].y) + (va[k].z + va[k].w);
-  }
-#pragma unroll
-  for (int k = 0; k < kHv; ++k) {
-    q[0] += (wu[k].x + wu[k].y) + (wu[k].z + wu[k].w);
-    q[1] += (wa[k].x + wa[k].y) + (wa[k].z + wa[k].w);
   }
   block_sum<kHeadCols>(h, scratch);
   block_sum<2>(q, scratch);
@@ -1027,20 +1046,17 @@ __device__ __forceinline__ void finish_step(const AdamArgs &a, int par, float *s
   }
 }
 
-// kRest: the second launch of a one-GPU step — rows the hot launch already updated carry -1 in the row map and
-// are skipped (word cleared); no finish.  !kRest: every row of [row_lo, n_rows) (multi-GPU parts, with finish
-// when parts & 4).
-template <bool kNT, bool kRest>
-__global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
-  __shared__ float scratch[kHeadCols * 16];
+// every row of [row_lo, n_rows); workgroup 0 finishes the step when parts & 4
+template <bool kNT>
+__device__ __forceinline__ void adam_body(const AdamArgs &a, int bid, int nblocks, float *scratch) {
   const int l = threadIdx.x & 31;
-  const int nhw = gridDim.x * 8;
-  const int step = a.sel[a.step_src];
+  const int nhw = nblocks * 8;
+  const int step = a.sel[0];
   const int par = step & 1;
   const float alpha = a.pub[par].alpha;
   const int32_t *rowmap = a.rowmap + (size_t)par * a.rows;
   float sq = 0.f, sqa = 0.f;  // sum(W_new^2) over user rows / anime rows of this thread
-  int r = a.row_lo + blockIdx.x * 8 + (threadIdx.x >> 5);
+  int r = a.row_lo + bid * 8 + (threadIdx.x >> 5);
   // two rows in flight per half-wave; the row-map words of the NEXT pair are fetched one
   // iteration ahead so a touched row's chunk partial is requested together with W/M/V
   int rm0 = 0, rm1 = 0;
@@ -1054,95 +1070,33 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     const int rn0 = r + 2 * nhw, rn1 = r + 3 * nhw;
     rm0 = rn0 < a.n_rows ? rowmap[rn0] : 0;
     rm1 = rn1 < a.n_rows ? rowmap[rn1] : 0;
-    const float q0 = row_finish<kNT>(a, par, r, l, alpha, x0, 0);
-    const float q1 = row_finish<kNT>(a, par, r1, l, alpha, x1, 0);
+    const float q0 = row_finish<kNT>(a, par, r, l, alpha, x0);
+    const float q1 = row_finish<kNT>(a, par, r1, l, alpha, x1);
     if (r < a.n_user_rows) sq += q0; else sqa += q0;
     if (r1 < a.n_user_rows) sq += q1; else sqa += q1;
   }
   if (r < a.n_rows) {
     RowLoad x0;
     row_issue<kNT>(a, par, r, l, rm0, x0);
-    const float q0 = row_finish<kNT>(a, par, r, l, alpha, x0, 0);
+    const float q0 = row_finish<kNT>(a, par, r, l, alpha, x0);
     if (r < a.n_user_rows) sq += q0; else sqa += q0;
   }
   float *rp = a.regpart + (size_t)(par * 2) * ANIREC_ADAM_BLOCKS;
-  block_sq_partials(sq, sqa, scratch, (a.parts & 1) ? rp + blockIdx.x : nullptr,
-                    (a.parts & 2) ? rp + ANIREC_ADAM_BLOCKS + blockIdx.x : nullptr);
-  if (!kRest && blockIdx.x == 0 && (a.parts & 4)) finish_step(a, par, scratch);
+  block_sq_partials(sq, sqa, scratch, (a.parts & 1) ? rp + bid : nullptr,
+                    (a.parts & 2) ? rp + ANIREC_ADAM_BLOCKS + bid : nullptr);
+  if (bid == 0 && (a.parts & 4)) finish_step(a, par, scratch);
 }
 
-// hot(t): the rows batch t+1 touches — one half-wave per chunk record of its prepared slot, the first chunk of a
-// row standing for the row — get their step-t update first (plain loads/stores: fwd/bwd(t+1) read them right
-// away), are marked -1 in the row map for the rest launch, and workgroup 0 finishes the step.  Any set of rows is
-// a valid hot set (every row is updated exactly once per step by hot or rest), so a slot that was prepared for
-// another step only costs speed, never correctness.
-struct HotArgs {
-  AdamArgs a;
-  char *arena;
-  size_t slot_bytes;
-  int cap, arena_steps, n_steps_total;
-};
-
-__global__ __launch_bounds__(256, 8) void k_adam_hot(HotArgs h) {  // one row per half-wave: lives on occupancy
+template <bool kNT>
+__global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
   __shared__ float scratch[kHeadCols * 16];
-  const AdamArgs &a = h.a;
-  // round trip 1: the step index and BOTH parities' step size together
-  const int step = a.sel[0];
-  const float alpha0 = a.pub[0].alpha, alpha1 = a.pub[1].alpha;
-  const int par = step & 1;
-  const float alpha = par ? alpha1 : alpha0;
-  const int l = threadIdx.x & 31;
-  const int hw = blockIdx.x * 8 + (threadIdx.x >> 5);
-  const int T = hw >= a.capC ? 1 : 0;
-  const int c = hw - T * a.capC;
-  float sq = 0.f, sqa = 0.f;
-  if (step + 1 < h.n_steps_total && hw < 2 * a.capC) {
-    Slot sl = slot_of(h.arena, h.slot_bytes, h.cap, a.capC, (step + 1) % h.arena_steps);
-    // round trip 2: the chunk record and the chunk count together (the record is read unconditionally: in bounds)
-    const int nch = sl.nchunks[T];
-    const int4 rec = sl.chunks[T * a.capC + c];
-    const int r = rec.x;
-    if (c < min(nch, a.capC) && rec.w > 0 && r >= 0 && r < a.rows) {
-      // round trip 3: the row map word and the three row streams together; 4 (touched rows): the chunk partial
-      RowLoad x;
-      const size_t e = (size_t)r * kRowVec + l;
-      const int rm = a.rowmap[(size_t)par * a.rows + r];
-      x.w = reinterpret_cast<const float4 *>(a.W)[e];
-      x.m = reinterpret_cast<const float4 *>(a.M)[e];
-      x.v = reinterpret_cast<const float4 *>(a.V)[e];
-      x.rm = rm > 0 ? rm : 0;
-      x.p0 = make_float4(0.f, 0.f, 0.f, 0.f);
-      x.s0 = 0.f;
-      if (rm > 0) {
-        const size_t first = (size_t)par * 2 * a.capC + ((rm - 1) >> 10);
-        x.p0 = reinterpret_cast<const float4 *>(a.P)[first * kRowVec + l];
-        x.s0 = a.S[first];
-      }
-      if (rm >= 0) {  // (< 0: a stale slot listed the row twice — already updated)
-        const float q = row_finish<false, 4>(a, par, r, l, alpha, x, -1);
-        if (r < a.n_user_rows) sq = q; else sqa = q;
-      }
-    }
-  }
-  float *rh = a.reghot + (size_t)(par * 2) * kHotBlocksMax;
-  block_sq_partials(sq, sqa, scratch, rh + blockIdx.x, rh + kHotBlocksMax + blockIdx.x);
-  // the rest launch of this step runs right behind this one on the same stream, possibly beside head(t+1) which
-  // moves sel[0] on: it takes its step index from a word only this launch writes
-  if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<int32_t *>(a.sel)[1] = step;
-}
-
-// the finish of a one-GPU step as a launch of its own (one workgroup): it needs the head partials of step t and
-// the L2 partials of step t-1 only, so the captured graph runs it BESIDE the hot launch (whose registers it would
-// otherwise inflate: the hot launch lives on occupancy)
-__global__ __launch_bounds__(256) void k_finish(AdamArgs a) {
-  __shared__ float scratch[kHeadCols * 16];
-  finish_step(a, a.sel[0] & 1, scratch);
+  adam_body<kNT>(a, blockIdx.x, gridDim.x, scratch);
 }
 
 // sum(W^2) partials of the CURRENT weights into both parities (after (re)loading weights, before validation):
 // the next step's finish reads them whatever its parity
 __global__ __launch_bounds__(256) void k_reg_init(const float *W, int row_lo, int n_rows, int n_user_rows,
-                                                  float *regpart, float *reghot) {
+                                                  float *regpart) {
   __shared__ float scratch[16];
   const int l = threadIdx.x & 31;
   const int nhw = gridDim.x * 8;
@@ -1164,7 +1118,6 @@ __global__ __launch_bounds__(256) void k_reg_init(const float *W, int row_lo, in
       regpart[(size_t)(p * 2 + 1) * ANIREC_ADAM_BLOCKS + blockIdx.x] = an;
     }
   }
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < 4 * kHotBlocksMax; i += gridDim.x * 256) reghot[i] = 0.f;
 }
 
 // flat Adam with an explicit gradient (unit-testable bit-exact stage)
@@ -1286,7 +1239,7 @@ static inline float *packet_ptr(const anirec_train_desc *d, int seg) {
   return d->packets + anirec_packet_floats(d->max_batch) * (size_t)seg;
 }
 
-static int launch_fwd(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
+static FwdArgs fwd_args(const anirec_train_desc *d, const TrainWs &w) {
   FwdArgs a;
   a.W = d->W;
   a.n_user_rows = d->n_user_rows;
@@ -1302,6 +1255,12 @@ static int launch_fwd(const anirec_train_desc *d, const TrainWs &w, hipStream_t 
   a.su = w.su;
   a.sa = w.sa;
   a.cap = d->max_batch;
+  return a;
+}
+
+static int launch_fwd(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
+  const FwdArgs a = fwd_args(d, w);
+  float *pk = packet_ptr(d, d->my_seg);
   hipLaunchKernelGGL(k_fwd, dim3((d->max_batch + 7) / 8), dim3(256), 0, s, a);
   if (d->n_seg > 1)
     hipLaunchKernelGGL(k_seg_stats, dim3(1), dim3(1024), 0, s, pk, packet_cap(d->max_batch), d->max_batch,
@@ -1309,7 +1268,7 @@ static int launch_fwd(const anirec_train_desc *d, const TrainWs &w, hipStream_t 
   return (int)hipGetLastError();
 }
 
-static int launch_head(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
+static HeadArgs head_args(const anirec_train_desc *d, const TrainWs &w) {
   HeadArgs a;
   a.state = d->state;
   a.sched = d->sched;
@@ -1325,8 +1284,16 @@ static int launch_head(const anirec_train_desc *d, const TrainWs &w, hipStream_t
   a.pub = w.pub;
   a.sel = w.sel;
   a.l2 = d->l2;
-  const int bps = (d->max_batch + kHeadThreads - 1) / kHeadThreads;
-  hipLaunchKernelGGL(k_head, dim3(bps * d->n_seg), dim3(kHeadThreads), 0, s, a);
+  return a;
+}
+
+static inline int head_blocks(const anirec_train_desc *d) {
+  return (d->max_batch + kHeadThreads - 1) / kHeadThreads * d->n_seg;
+}
+
+static int launch_head(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
+  const HeadArgs a = head_args(d, w);
+  hipLaunchKernelGGL(k_head, dim3(head_blocks(d)), dim3(kHeadThreads), 0, s, a);
   return (int)hipGetLastError();
 }
 
@@ -1350,7 +1317,7 @@ static int launch_densify(const anirec_train_desc *d, const TrainWs &w, hipStrea
 
 // bwd only (the densify pass of the multi-GPU modes is a separate launch so that the caller can fork work
 // that needs the chunk partials but not the dense buffer)
-static int launch_bwd_only(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
+static BwdArgs bwd_args(const anirec_train_desc *d, const TrainWs &w) {
   BwdArgs a;
   a.W = d->W;
   a.pub = w.pub;
@@ -1369,6 +1336,11 @@ static int launch_bwd_only(const anirec_train_desc *d, const TrainWs &w, hipStre
   a.P = w.P;
   a.S = w.S;
   a.rowmap = d->rowmap;
+  return a;
+}
+
+static int launch_bwd_only(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
+  const BwdArgs a = bwd_args(d, w);
   hipLaunchKernelGGL(k_bwd, dim3((2 * w.capC + 7) / 8), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
@@ -1389,7 +1361,6 @@ static inline int adam_grid(const anirec_train_desc *d) {
   if (b > ANIREC_ADAM_BLOCKS) b = ANIREC_ADAM_BLOCKS;
   return (int)b;
 }
-static inline int hot_grid(const TrainWs &w) { return (2 * w.capC + 7) / 8; }
 
 static AdamArgs adam_args(const anirec_train_desc *d, const TrainWs &w) {
   AdamArgs a;
@@ -1402,11 +1373,8 @@ static AdamArgs adam_args(const anirec_train_desc *d, const TrainWs &w) {
   a.rows = table_rows(d);
   a.capC = w.capC;
   a.parts = 7;
-  a.step_src = 0;
   a.dense_lo = dense_lo_of(d);
   a.dense_rows = d->dense_rows;
-  a.rest_blocks = adam_grid(d);
-  a.hot_blocks = d->dense_mode ? 0 : hot_grid(w);
   a.rowmap = d->rowmap;
   a.P = w.P;
   a.S = w.S;
@@ -1418,7 +1386,6 @@ static AdamArgs adam_args(const anirec_train_desc *d, const TrainWs &w) {
   a.hpart_stride = w.hpart_stride;
   a.two_l2 = 2.0f * d->l2;
   a.regpart = w.regpart;
-  a.reghot = w.reghot;
   return a;
 }
 
@@ -1428,37 +1395,7 @@ static inline bool stream_nt(const anirec_train_desc *d) {
   return (size_t)table_rows(d) * kDim * 4 * 3 > ((size_t)192 << 20);
 }
 
-// One GPU: hot(t) — the rows of batch t+1 + the step finish; rest(t) — every other row.
-static int launch_adam_hot(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
-  HotArgs h;
-  h.a = adam_args(d, w);
-  h.arena = w.arena;
-  h.slot_bytes = w.slot_bytes;
-  h.cap = w.cap;
-  h.arena_steps = w.arena_steps;
-  h.n_steps_total = d->n_steps;
-  hipLaunchKernelGGL(k_adam_hot, dim3(hot_grid(w)), dim3(256), 0, s, h);
-  return (int)hipGetLastError();
-}
-
-static int launch_finish(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
-  const AdamArgs a = adam_args(d, w);
-  hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, a);
-  return (int)hipGetLastError();
-}
-
-static int launch_adam_rest(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
-  AdamArgs a = adam_args(d, w);
-  a.parts = 3;
-  a.step_src = 1;
-  if (stream_nt(d))
-    hipLaunchKernelGGL((k_adam<true, true>), dim3(adam_grid(d)), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL((k_adam<false, true>), dim3(adam_grid(d)), dim3(256), 0, s, a);
-  return (int)hipGetLastError();
-}
-
-// Multi-GPU (dense_mode != 0).  which: 0 = every row this rank updates + finish, 1 = the user rows only (may
+// which: 0 = every row this rank updates + finish (one GPU; replicated multi-GPU modes), 1 = the user rows only (may
 // run while the anime gradient is still in the all-reduce: user-sharded mode), 2 = the anime rows + finish
 static int launch_adam_full(const anirec_train_desc *d, const TrainWs &w, hipStream_t s, int which) {
   AdamArgs a = adam_args(d, w);
@@ -1474,17 +1411,14 @@ static int launch_adam_full(const anirec_train_desc *d, const TrainWs &w, hipStr
     a.parts = 2 | 4;
   }
   if (stream_nt(d))
-    hipLaunchKernelGGL((k_adam<true, false>), dim3(adam_grid(d)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_adam<true>), dim3(adam_grid(d)), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((k_adam<false, false>), dim3(adam_grid(d)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_adam<false>), dim3(adam_grid(d)), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
 
 static int launch_adam(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
-  if (d->dense_mode) return launch_adam_full(d, w, s, 0);
-  int e = launch_finish(d, w, s);
-  if (!e) e = launch_adam_hot(d, w, s);
-  return e ? e : launch_adam_rest(d, w, s);
+  return launch_adam_full(d, w, s, 0);
 }
 
 }  // namespace anirec
@@ -1515,8 +1449,7 @@ int anirec_train_init_reg(const anirec_train_desc *d, void *stream) {
     lo = d->adam_row_lo;
     hi = d->adam_row_hi;
   }
-  hipLaunchKernelGGL(k_reg_init, dim3(adam_grid(d)), dim3(256), 0, s, d->W, lo, hi, d->n_user_rows, w.regpart,
-                     w.reghot);
+  hipLaunchKernelGGL(k_reg_init, dim3(adam_grid(d)), dim3(256), 0, s, d->W, lo, hi, d->n_user_rows, w.regpart);
   ANIREC_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(k_sum_regpart, dim3(1), dim3(1024), 0, s, d->state, w.regpart);
   return (int)hipGetLastError();
@@ -1581,25 +1514,54 @@ int anirec_train_adam(const anirec_train_desc *d, void *stream) {
   return launch_adam(d, carve(d->workspace, d->max_batch, d->arena_steps), (hipStream_t)stream);
 }
 
+// Measurement hook (bench.py): average duration [ms] of one of the three idempotent stages of the CURRENT step
+// (0 fwd, 1 head, 2 bwd: same inputs -> same outputs however often they run), `reps` launches captured into a
+// throw-away graph and replayed once between two HIP events.  Eager launches from the host cannot time 5-10 us
+// kernels: the host falls behind and the events measure its latency.  Synchronises the stream.
+int anirec_train_stage_time(const anirec_train_desc *d, int32_t stage, int32_t reps, float *avg_ms_host, void *stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!avg_ms_host || reps < 1 || stage < 0 || stage > 2 || !stream) return ANIREC_EINVAL;
+  if (!d->user_idx || !d->anime_idx || !d->rating || !d->sched) return ANIREC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  TrainWs w = carve(d->workspace, d->max_batch, d->arena_steps);
+  hipGraph_t g = nullptr;
+  hipGraphExec_t ex = nullptr;
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) return ANIREC_ECAPTURE;
+  int e = 0;
+  for (int i = 0; i < reps && !e; ++i)
+    e = stage == 0 ? launch_fwd(d, w, s) : stage == 1 ? launch_head(d, w, s) : launch_bwd_only(d, w, s);
+  hipError_t ce = hipStreamEndCapture(s, &g);
+  if (e || ce != hipSuccess || !g || hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
+    if (g) (void)hipGraphDestroy(g);
+    return e ? e : ANIREC_ECAPTURE;
+  }
+  (void)hipGraphDestroy(g);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  float ms = 0.f;
+  hipError_t he = hipEventCreate(&e0);
+  if (he == hipSuccess) he = hipEventCreate(&e1);
+  if (he == hipSuccess) he = hipGraphLaunch(ex, s);          // warm
+  if (he == hipSuccess) he = hipEventRecord(e0, s);
+  if (he == hipSuccess) he = hipGraphLaunch(ex, s);
+  if (he == hipSuccess) he = hipEventRecord(e1, s);
+  if (he == hipSuccess) he = hipEventSynchronize(e1);
+  if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipGraphExecDestroy(ex);
+  if (he != hipSuccess) return (int)he;
+  *avg_ms_host = ms / (float)reps;
+  return ANIREC_OK;
+}
+
 int anirec_train_adam_part(const anirec_train_desc *d, int32_t which, void *stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   TrainWs w = carve(d->workspace, d->max_batch, d->arena_steps);
   hipStream_t s = (hipStream_t)stream;
-  switch (which) {
-    case 1:  // multi-GPU, user-sharded: the user rows
-    case 2:  // ... the anime rows + finish
-      if (d->dense_mode != 1) return ANIREC_EINVAL;
-      return launch_adam_full(d, w, s, which);
-    case 3:  // one GPU: hot rows + finish
-    case 4:  // one GPU: the rest
-      if (d->dense_mode != 0) return ANIREC_EINVAL;
-      if (which == 4) return launch_adam_rest(d, w, s);
-      if (int e = launch_finish(d, w, s)) return e;
-      return launch_adam_hot(d, w, s);
-    default:
-      return ANIREC_EINVAL;
-  }
+  if ((which != 1 && which != 2) || d->dense_mode != 1) return ANIREC_EINVAL;
+  return launch_adam_full(d, w, s, which);
 }
 
 // ---- multi-GPU step halves (one C call each; the caller issues the two collectives between them) ----------
@@ -1675,8 +1637,6 @@ struct anirec_trainer {
   TrainWs ws;
   hipGraphExec_t exec;
   int graph_steps;
-  hipStream_t side;         // second graph branch: finish(t), then fwd/head/bwd(t+1) beside rest(t)
-  hipEvent_t fork, fork2, join;
 };
 
 int anirec_trainer_create(const anirec_train_desc *d, anirec_trainer **out) {
@@ -1690,15 +1650,6 @@ int anirec_trainer_create(const anirec_train_desc *d, anirec_trainer **out) {
   t->ws = carve(d->workspace, d->max_batch, d->arena_steps);
   t->exec = nullptr;
   t->graph_steps = 0;
-  t->side = nullptr;
-  t->fork = t->fork2 = t->join = nullptr;
-  if (hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&t->fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&t->fork2, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&t->join, hipEventDisableTiming) != hipSuccess) {
-    anirec_trainer_destroy(t);
-    return ANIREC_ENODEVICE;
-  }
   *out = t;
   return ANIREC_OK;
 }
@@ -1706,10 +1657,6 @@ int anirec_trainer_create(const anirec_train_desc *d, anirec_trainer **out) {
 int anirec_trainer_destroy(anirec_trainer *t) {
   if (!t) return ANIREC_EINVAL;
   if (t->exec) (void)hipGraphExecDestroy(t->exec);
-  if (t->fork) (void)hipEventDestroy(t->fork);
-  if (t->fork2) (void)hipEventDestroy(t->fork2);
-  if (t->join) (void)hipEventDestroy(t->join);
-  if (t->side) (void)hipStreamDestroy(t->side);
   delete t;
   return ANIREC_OK;
 }
@@ -1724,41 +1671,13 @@ static int front_of_step(anirec_trainer *t, hipStream_t s) {
 static int one_step(anirec_trainer *t, hipStream_t s) {
   int e;
   if ((e = front_of_step(t, s))) return e;
-  if ((e = launch_finish(&t->d, t->ws, s))) return e;
-  if ((e = launch_adam_hot(&t->d, t->ws, s))) return e;
-  return launch_adam_rest(&t->d, t->ws, s);
-}
-
-// G steps as a two-branch chain (s = main stream, side = second branch):
-//     front(0)  { hot(0) || finish(0) }  { rest(0) || front(1) }  { hot(1) || finish(1) }  { rest(1) || front(2) } ...
-// front(t+1) = fwd/head/bwd of step t+1 only reads rows that hot(t) has updated, the scalars finish(t) has
-// written, and writes the other parity's scratch, so it runs beside the long rest(t) stream; hot(t+1) needs
-// both rest(t) (every row it touches must have had its step-t update) and front(t+1).
-static int overlapped_steps(anirec_trainer *t, int G, hipStream_t s) {
-  int e = front_of_step(t, s);
-  for (int i = 0; i < G && !e; ++i) {
-    ANIREC_HIP_CHECK(hipEventRecord(t->fork, s));            // bwd(i) [and rest(i-1)] done
-    ANIREC_HIP_CHECK(hipStreamWaitEvent(t->side, t->fork, 0));
-    if ((e = launch_finish(&t->d, t->ws, t->side))) break;    // side: finish(i)
-    if ((e = launch_adam_hot(&t->d, t->ws, s))) break;        // main: hot(i)
-    const bool more = i + 1 < G;
-    if (more) {
-      ANIREC_HIP_CHECK(hipEventRecord(t->fork2, s));          // hot(i) done
-      ANIREC_HIP_CHECK(hipStreamWaitEvent(t->side, t->fork2, 0));
-      if ((e = front_of_step(t, t->side))) break;             // side: front(i+1), after finish(i) and hot(i)
-    }
-    ANIREC_HIP_CHECK(hipEventRecord(t->join, t->side));
-    if ((e = launch_adam_rest(&t->d, t->ws, s))) break;       // main: rest(i)
-    ANIREC_HIP_CHECK(hipStreamWaitEvent(s, t->join, 0));      // both branches meet before hot(i+1) / the graph's end
-  }
-  return e;
+  return launch_adam(&t->d, t->ws, s);
 }
 
 // Runs steps [first_step, first_step + n_steps); first_step must equal the device cursor
 // (state->step_fwd).  The batch prep (sort + chunk tables) is driven from here: with use_graph a
 // captured graph of G steps starts with the prep of the G steps AFTER it (relative to the device
-// cursor), so a replay needs no host work between blocks; the arena holds 2G steps.  hot(t) reads the
-// prepared slot of step t+1: every path below has it prepared before step t runs.
+// cursor), so a replay needs no host work between blocks; the arena holds 2G steps.
 int anirec_trainer_run(anirec_trainer *t, int32_t first_step, int32_t n_steps, int32_t use_graph,
                        void *stream) {
   if (!t || n_steps < 0 || first_step < 0 || first_step + n_steps > t->d.n_steps) return ANIREC_EINVAL;
@@ -1768,21 +1687,6 @@ int anirec_trainer_run(anirec_trainer *t, int32_t first_step, int32_t n_steps, i
   int G = t->d.arena_steps / 2;
   if (G > 32) G = 32;
   int done = 0;
-  // ANIREC_TRAIN_MODE (A/B on one box): "graph_serial" = the captured graph without the second branch,
-  // "eager_overlap" = the two-branch chain launched eagerly on two streams (no graph)
-  const char *tm = getenv("ANIREC_TRAIN_MODE");
-  const bool serial_graph = tm && tm[0] == 'g' && tm[6] == 's';
-  if (tm && tm[0] == 'e' && use_graph && s != nullptr) {
-    while (done < n_steps) {
-      int blk = n_steps - done;
-      if (blk > t->d.arena_steps - 1) blk = t->d.arena_steps - 1;
-      int e = launch_prep(&t->d, t->ws, first_step + done, blk + 1, false, s);
-      if (!e) e = overlapped_steps(t, blk, s);
-      if (e) return e;
-      done += blk;
-    }
-    return ANIREC_OK;
-  }
   const bool graph = use_graph && s != nullptr && G >= 4 && n_steps >= G;
   if (graph) {
     if (!t->exec || t->graph_steps != G) {
@@ -1792,8 +1696,7 @@ int anirec_trainer_run(anirec_trainer *t, int32_t first_step, int32_t n_steps, i
       if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess)
         return ANIREC_ECAPTURE;
       int e = launch_prep(&t->d, t->ws, G, G, true, s);  // steps cursor+G .. cursor+2G
-      if (!e && !serial_graph) e = overlapped_steps(t, G, s);
-      for (int i = 0; serial_graph && i < G && !e; ++i) e = one_step(t, s);
+      for (int i = 0; i < G && !e; ++i) e = one_step(t, s);
       hipError_t ce = hipStreamEndCapture(s, &g);
       if (e || ce != hipSuccess || !g) {
         if (g) (void)hipGraphDestroy(g);
@@ -1813,14 +1716,13 @@ int anirec_trainer_run(anirec_trainer *t, int32_t first_step, int32_t n_steps, i
       ANIREC_HIP_CHECK(hipGraphLaunch(t->exec, s));
       done += G;
     }
-    // the last replay already prepared steps [first_step+done, first_step+done+G): the tail (< G steps, and
-    // the slot after its last step) is covered
+    // the last replay already prepared steps [first_step+done, first_step+done+G): the tail is covered
   }
   while (done < n_steps) {
     int blk = n_steps - done;
-    if (!(graph && done > 0)) {  // no replay before: prepare from the host, one slot beyond the block
-      if (blk > t->d.arena_steps - 1) blk = t->d.arena_steps - 1;
-      int e = launch_prep(&t->d, t->ws, first_step + done, blk + 1, false, s);
+    if (!(graph && done > 0)) {  // no replay before: prepare arena-sized blocks from the host
+      if (blk > t->d.arena_steps) blk = t->d.arena_steps;
+      int e = launch_prep(&t->d, t->ws, first_step + done, blk, false, s);
       if (e) return e;
     }
     for (int i = 0; i < blk; ++i) {

@@ -223,13 +223,13 @@ class TrainEngine:
     def adam_anime_finish(self):
         _lib.check(self.lib.anirec_train_adam_part(C.byref(self.desc), 2, self._sp()), "anirec_train_adam_part")
 
-    def adam_hot(self):
-        """One GPU: the rows the next batch touches + the step finish (k_adam_hot)."""
-        _lib.check(self.lib.anirec_train_adam_part(C.byref(self.desc), 3, self._sp()), "anirec_train_adam_part")
-
-    def adam_rest(self):
-        """One GPU: every other row (the long HBM stream)."""
-        _lib.check(self.lib.anirec_train_adam_part(C.byref(self.desc), 4, self._sp()), "anirec_train_adam_part")
+    def stage_time(self, stage, reps=50):
+        """Average duration [ms] of `reps` back-to-back launches of an idempotent stage of the current step
+        ("fwd", "head" or "bwd"), timed inside a captured graph (bench.py's per-kernel figures)."""
+        ms = C.c_float(0.0)
+        _lib.check(self.lib.anirec_train_stage_time(C.byref(self.desc), ("fwd", "head", "bwd").index(stage), int(reps),
+                                                    C.byref(ms), self._sp()), "anirec_train_stage_time")
+        return float(ms.value)
 
     # ---- multi-GPU step halves: one C call each, the collectives go between them ------------
     def _get_stepper(self):
@@ -327,10 +327,10 @@ def workspace_layout(max_batch, arena_steps):
     capC = (cap + cap // _lib.CHUNK + 2 + 3) & ~3
     off = 0
     lay = {"cap": cap, "capC": capC}
-    # hpart, pub, regpart, reghot, P, S hold two copies (step parity 0 then 1)
+    # hpart, pub, regpart, P, S hold two copies (step parity 0 then 1)
     for name, nbytes in (("su", 4 * cap), ("sa", 4 * cap), ("dy", 4 * cap),
                          ("hpart", 2 * 4 * 8 * _lib.MAX_SEG * ((cap + 255) // 256)), ("pub", 2 * 64), ("sel", 16),
-                         ("regpart", 4 * 4 * _lib.ADAM_BLOCKS), ("reghot", 4 * 4 * _lib.HOT_BLOCKS_MAX),
+                         ("regpart", 4 * 4 * _lib.ADAM_BLOCKS),
                          ("P", 2 * 4 * 2 * capC * DIM), ("S", 2 * 4 * 2 * capC)):
         lay[name] = (off, nbytes)
         off += _align(nbytes)

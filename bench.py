@@ -110,63 +110,61 @@ def run_single(workload, steps, warmup, batch, use_graph=True, cpu_baseline=True
     rec = eng.read_state()
     assert int(rec["step_fwd"]) == warmup + steps and np.isfinite(rec["last_loss"])
 
-    # instrumented pass: the same K steps' worth of work, stage by stage, HIP events on the
-    # engine's stream around every launch of each kernel.  adam = hot (the rows batch t+1 touches + the step
-    # finish) then rest (every other row: the long HBM stream, the dominant kernel).
-    stages = ("fwd", "head", "bwd", "adam_hot", "adam_rest")
-    evs = {k: [] for k in stages}
+    # instrumented pass over the same K steps' worth of work.  k_adam (the dominant kernel): HIP events on the
+    # engine's stream around every launch, the steps run eagerly stage by stage (the host is far ahead of a 190 us
+    # kernel).  The three small kernels (5-10 us, shorter than an eager launch from Python: events around them
+    # would time the host): each repeated 50 x inside a captured graph on the batch of a prepared step
+    # (anirec_train_stage_time; they are idempotent), sampled at 8 steps of the pass.
+    evs = []
+    small = {"fwd": [], "head": [], "bwd": []}
     first = warmup + steps
     done = 0
+    sample_every = max(1, steps // 8)
     while done < steps:
-        blk = min(eng.arena_steps - 1, steps - done)
-        eng.prep(first + done, min(blk + 1, total_steps - (first + done)))    # hot(t) reads the slot of step t+1
-        for _ in range(blk):
-            for name in stages:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record(eng.stream)
-                getattr(eng, name)()
-                e1.record(eng.stream)
-                evs[name].append((e0, e1))
+        blk = min(eng.arena_steps, steps - done)
+        eng.prep(first + done, blk)
+        for k in range(blk):
+            eng.fwd()
+            eng.head()
+            eng.bwd()
+            if (done + k) % sample_every == 0:
+                for name in small:
+                    small[name].append(eng.stage_time(name))
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(eng.stream)
+            eng.adam()
+            e1.record(eng.stream)
+            evs.append((e0, e1))
         done += blk
     eng.synchronize()
-    kern_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in evs.items()}
+    kern_ms = {k: float(np.mean(v)) for k, v in small.items()}
+    kern_ms["adam"] = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     rows = n_users + n_anime
-    # rows the rest launch streams = all rows minus the hot set (distinct rows of the NEXT batch), averaged over the
-    # instrumented steps (the last one has no next batch: its hot set is empty)
-    hot = []
-    for k in range(first + 1, min(first + steps + 1, total_steps)):
-        sl = slice(k * batch, (k + 1) * batch)
-        hot.append(int(torch.unique(ui[sl]).numel() + torch.unique(ai[sl]).numel()))
-    hot_rows = float(np.mean(hot + [0] * (steps - len(hot)))) if steps else 0.0
-    rest_bytes = ADAM_BYTES_PER_ELEM * (rows - hot_rows) * 128
     adam_bytes = ADAM_BYTES_PER_ELEM * rows * 128
-    rest_gbs = rest_bytes / (kern_ms["adam_rest"] * 1e-3) / 1e9
+    adam_gbs = adam_bytes / (kern_ms["adam"] * 1e-3) / 1e9
     # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (PMC cannot be collected
     # from inside this process); quoted only for the workload it was measured on AND only while the kernel source
     # is still the one that was measured (git blob hash recorded next to the counters)
     traffic = None
     if workload == "s109m" and batch == 10_000:
-        traffic = pmc_traffic("train_s109m", "k_adam<true, true>", source="anirec_train.hip")
+        traffic = pmc_traffic("train_s109m", "k_adam<true>", source="anirec_train.hip")
     step_bytes = (FWD_BYTES_PER_RATING + BWD_BYTES_PER_RATING) * batch + adam_bytes
     out = {
         "value": steps * batch / dt,
         "ms_per_step": dt / steps * 1e3,
         "loss": float(rec["last_loss"]),
         "kernels_ms": kern_ms,
-        "hot_rows_per_step": hot_rows,
-        "roofline": {"kernel": "k_adam<rest> (dense fused Adam over the %.0f rows the next batch does not touch; the "
-                               "other %.0f rows are updated by k_adam_hot)" % (rows - hot_rows, hot_rows),
-                     "bound": "hbm", "achieved": rest_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": rest_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": rest_bytes,
-                     "avg_launch_ms": kern_ms["adam_rest"]},
+        "roofline": {"kernel": "k_adam (dense fused Adam, both tables)", "bound": "hbm",
+                     "achieved": adam_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": adam_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": adam_bytes,
+                     "avg_launch_ms": kern_ms["adam"]},
         # whole-step roofline of SURVEY.md §8(d): (3.1 KB x B + 28 B x table elements) / step time
         "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_step": step_bytes,
                           "achieved": step_bytes / (dt / steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS,
-                          # what the graph hides: sum of the five kernels run one after the other vs the step
-                          "serial_kernels_ms": float(sum(kern_ms.values()))},
+                          "sum_of_kernels_ms": float(sum(kern_ms.values()))},
         "fwd_gbs": FWD_BYTES_PER_RATING * batch / (kern_ms["fwd"] * 1e-3) / 1e9,
         "bwd_gbs": BWD_BYTES_PER_RATING * batch / (kern_ms["bwd"] * 1e-3) / 1e9,
     }
@@ -645,7 +643,7 @@ def main():
         "roofline": res["roofline"],
         "step_roofline": res["step_roofline"],
         "cpu_baseline": res.get("cpu_baseline"),
-        "kernels_ms": res["kernels_ms"], "hot_rows_per_step": res["hot_rows_per_step"],
+        "kernels_ms": res["kernels_ms"],
         "embed_fwd_GBps": res["fwd_gbs"], "embed_bwd_GBps": res["bwd_gbs"],
         "final_loss": res["loss"],
     }

@@ -162,12 +162,12 @@ int anirec_train_fwd(const anirec_train_desc *d, void *stream);
 int anirec_train_head(const anirec_train_desc *d, void *stream);
 int anirec_train_bwd(const anirec_train_desc *d, void *stream);
 int anirec_train_adam(const anirec_train_desc *d, void *stream);
-/* adam as two launches.
- *   dense_mode 1: which == 1 updates the user rows (may run while the anime gradient is still in the
- *     all-reduce), which == 2 the anime rows and finishes the step.
- *   dense_mode 0: which == 3 ("hot") updates the rows the NEXT batch touches (the prepared slot of step t+1)
- *     and finishes the step; which == 4 ("rest") every other row.  fwd/head/bwd of step t+1 only read hot rows,
- *     so they may run beside the rest launch — anirec_trainer_run's graph does exactly that. */
+/* Measurement hook (bench.py): average duration [ms] of `reps` back-to-back launches (captured into a graph) of
+ * one idempotent stage of the current step — 0 fwd, 1 head, 2 bwd.  Synchronises the stream. */
+int anirec_train_stage_time(const anirec_train_desc *d, int32_t stage, int32_t reps, float *avg_ms_host, void *stream);
+
+/* adam as two launches (dense_mode 1): which == 1 updates the user rows (may run while the anime gradient is
+ * still in the all-reduce), which == 2 the anime rows and finishes the step. */
 int anirec_train_adam_part(const anirec_train_desc *d, int32_t which, void *stream);
 
 /* Multi-GPU step as three C calls and two collectives (dense_mode 1 or 2; the stepper owns a side stream):
@@ -185,7 +185,7 @@ int anirec_dist_step_back(anirec_dist_stepper *h, void *stream);
 /* Steps [first_step, first_step + n_steps) — prep, fwd, head, bwd, adam — on one GPU; first_step
  * must equal the device cursor state->step_fwd.  use_graph != 0 replays a captured hipGraph of
  * G = min(32, arena_steps/2) steps whose first node prepares the G steps after it, so no host
- * work is needed between replays; inside the graph rest(t) and fwd/head/bwd(t+1) are parallel branches. */
+ * work is needed between replays. */
 typedef struct anirec_trainer anirec_trainer; /* host-side handle: descriptor copy + graph cache */
 int anirec_trainer_create(const anirec_train_desc *d, anirec_trainer **out_host);
 int anirec_trainer_destroy(anirec_trainer *t);

@@ -69,11 +69,11 @@ def _train_s7m(steps, use_graph):
     return out, A.cpu().numpy(), ai.cpu().numpy()
 
 
-def test_s7m_shape_graph_overlap_is_bitwise_the_serial_run_and_untouched_rows_are_bit_exact():
-    """BASELINE configs[1] table shape (15 000 x 17 560, B = 10 000): ~40 % of the rows are touched by the NEXT
-    batch, so the graph's second branch (fwd/head/bwd of step t+1 beside the rest launch of step t) is exercised
-    hard — any row read before its update, or scratch overwritten too early, changes bits."""
-    steps = 70                                         # two 32-step graph replays + a 6-step tail
+def test_s7m_shape_graph_is_bitwise_the_eager_run_and_untouched_rows_are_bit_exact():
+    """BASELINE configs[1] table shape (15 000 x 17 560, B = 10 000): the captured-graph loop (two 32-step replays +
+    a 6-step eager tail) against the eager loop, bit for bit, and the dense-only Adam update of rows no batch
+    touched against the oracle."""
+    steps = 70
     (W0, M0, V0, rec0, rm0), A0, ai = _train_s7m(steps, use_graph=False)
     assert (rm0 == 0).all() and np.isfinite(rec0["last_loss"]) and int(rec0["step_fwd"]) == steps
     for _ in range(2):
