@@ -94,7 +94,7 @@ def cosine_topk(What, queries, k, exclude_self=True, keep=None, workspace=None):
     return out_i, out_s
 
 
-def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=65536, fallback=True):
+def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=131072, fallback=True):
     """cosine_topk on the matrix cores (fp16 MFMA candidates + exact fp32 re-rank); rows the
     kernel could not prove complete are transparently re-run through the exact kernels.
     ``What`` must hold unit-norm rows (``rownorm`` output, as at every reference call site): the MFMA error

@@ -254,11 +254,11 @@ def _cosine_leg(W, nq, k, cpu_baseline, reps=3, slice_note=None, traffic_name=No
     dt = (time.perf_counter() - t0) / reps
     flops = 2.0 * nq * n * 128
     # roofline leg: HIP events around the k_cand launches (on the stream they run on), one extra call; with more
-    # than 65 536 queries the op runs in query batches and the hook reports the LAST batch, so time batch by batch
+    # than 131 072 queries the op runs in query batches and the hook reports the LAST batch, so time batch by batch
     cand_ms, cand_launches = 0.0, 0
-    for q0 in range(0, nq, 65536):
+    for q0 in range(0, nq, 131072):
         ops.topk_mfma_timing(True)
-        ops.cosine_topk_mfma(Wh, q[q0:q0 + 65536], k)
+        ops.cosine_topk_mfma(Wh, q[q0:q0 + 131072], k)
         ms, nl = ops.topk_mfma_timing(False)
         cand_ms += ms
         cand_launches += nl
