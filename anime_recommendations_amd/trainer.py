@@ -7,6 +7,7 @@ All arithmetic of a step runs in libanirec (HIP); this file only sequences epoch
 """
 from __future__ import annotations
 
+import time
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -55,6 +56,7 @@ class FitResult:
     best_epoch: int = -1
     stopped_epoch: int = -1
     optimizer: dict = field(default_factory=dict)
+    step_loop_seconds: list = field(default_factory=list)   # per epoch: wall time of the step loop alone (synchronised)
 
 
 def init_weights(n_users, n_anime, dim=128, seed=0):
@@ -115,6 +117,7 @@ def fit(table: RatingTable, cfg: FitConfig, engine=None, log=print, device="cuda
     best_w = None
     best_epoch, stopped, wait = -1, -1, 0
     t_global = 0
+    loop_s = []
     for epoch in range(cfg.epochs):
         lr = cfg.lr(epoch)
         gen.manual_seed(cfg.seed * 1_000_003 + epoch)
@@ -129,7 +132,11 @@ def fit(table: RatingTable, cfg: FitConfig, engine=None, log=print, device="cuda
             eu, ea, et = ops.gather_ratings(ui, ai, rt, perm)
             engine.set_epoch(eu, ea, et, starts, counts, alphas)
         engine.reset_metrics()
+        engine.synchronize()
+        t_loop = time.perf_counter()
         engine.run(n_steps, use_graph=cfg.use_graph)
+        engine.synchronize()
+        loop_s.append(time.perf_counter() - t_loop)
         t_global += n_steps
         loss, mse = engine.epoch_metrics()
         val_loss, val_mse = engine.evaluate(vu, va, vt)
@@ -156,7 +163,7 @@ def fit(table: RatingTable, cfg: FitConfig, engine=None, log=print, device="cuda
     engine.synchronize()
     rec = engine.read_state()
     res = FitResult(history=hist, U=engine.U.cpu().numpy().copy(), A=engine.A.cpu().numpy().copy(),
-                    head=head_of(rec), best_epoch=best_epoch, stopped_epoch=stopped)
+                    head=head_of(rec), best_epoch=best_epoch, stopped_epoch=stopped, step_loop_seconds=loop_s)
     if hasattr(engine, "optimizer_state"):       # Adam m, v and the step count of the LAST epoch (model.save)
         res.optimizer = engine.optimizer_state(iterations=t_global)
     if best_w is not None:

@@ -1,0 +1,58 @@
+"""gpurun_out/<round>/<workload>_{stats,fetch,write}/ (scripts/collect_profiles.sh) -> profiles/<round>_*:
+  <round>_<workload>_kernel_stats.csv   per-kernel Calls / TotalDurationNs / AverageNs / ... of the libanirec kernels
+  <round>_pmc_traffic_<workload>.json   HBM bytes per launch and kernel: FETCH_SIZE x 2 (gfx950 counts half of a wide
+                                        coalesced read) + WRITE_SIZE, unit KiB (MI355X_MICROARCH.md, HBM), stamped with
+                                        the git blob hash of every kernel source so that bench.py can tell a stale file.
+usage: python scripts/summarise_profiles.py r02 train topk100 ...   (bench.py reads `train` as train_s109m)"""
+import csv, glob, hashlib, json, os, sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd, works = sys.argv[1], sys.argv[2:]
+NAMES = {"train": "train_s109m", "topk100": "cosine_topk_k100", "topk10": "cosine_topk_k10", "topkall": "cosine_topk_allpairs_k100",
+         "topk18k": "cosine_topk_18k_k100", "pgrid": "pgrid", "ptk": "ptk", "ingest": "ingest", "recs": "recs"}
+
+
+def blob(path):        # `git hash-object`
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def short(n):
+    return n.split("(")[0].replace("void ", "").replace("anirec::", "")
+
+
+sources = {os.path.basename(f): blob(f) for f in sorted(glob.glob(os.path.join(ROOT, "anime_recommendations_amd/csrc/*.h*")))}
+for w in works:
+    base = os.path.join(ROOT, "gpurun_out", rnd, w)
+    name = NAMES.get(w, w)
+    st = glob.glob(base + "_stats/*kernel_stats.csv")
+    if st:
+        rows = [r for r in csv.DictReader(open(st[0])) if "anirec" in r["Name"]]
+        if rows:
+            with open(os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (rnd, name)), "w", newline="") as f:
+                wr = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+                wr.writeheader()
+                wr.writerows(rows)
+    out = defaultdict(dict)
+    for cn, sub, mul in (("FETCH_SIZE", "fetch", 2048.0), ("WRITE_SIZE", "write", 1024.0)):
+        f = glob.glob(base + "_%s/*counter_collection.csv" % sub)
+        if not f:
+            continue
+        acc = defaultdict(list)
+        for r in csv.DictReader(open(f[0])):
+            if "anirec" in r["Kernel_Name"] and r["Counter_Name"] == cn:
+                acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]) * mul)
+        for k, v in acc.items():
+            out[k]["launches"] = len(v)
+            out[k][sub + "_bytes_per_launch"] = sum(v) / len(v)
+            out[k][sub + "_bytes_all_launches"] = sum(v)
+    if out:
+        for k in out:
+            out[k]["total_bytes_per_launch"] = out[k].get("fetch_bytes_per_launch", 0) + out[k].get("write_bytes_per_launch", 0)
+            out[k]["total_bytes_all_launches"] = out[k].get("fetch_bytes_all_launches", 0) + out[k].get("write_bytes_all_launches", 0)
+        json.dump({"workload": name, "kernels": out, "sources": sources,
+                   "note": "two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) with --kernel-trace only; FETCH_SIZE x2 "
+                           "(gfx950), unit KiB; `sources` = git blob hashes of the kernel sources measured"},
+                  open(os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (rnd, name)), "w"), indent=1)
+    print(w, "->", name, sorted(out))
