@@ -251,48 +251,49 @@ __global__ __launch_bounds__(1024) void k_scan_spine(int32_t *bsum, int nb, int6
     run += x;
   }
 }
-__global__ __launch_bounds__(256) void k_scan_apply(const uint8_t *flags, const int32_t *bsum, int32_t *pos) {
-  __shared__ int wsum[4];
-  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const uint4 v = reinterpret_cast<const uint4 *>(flags)[t];
-  const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
-  const int mine = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
-  int incl = mine;  // inclusive scan over the wave
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int y = __shfl_up(incl, o, 64);
-    if (lane_id() >= o) incl += y;
-  }
-  if (lane_id() == 63) wsum[threadIdx.x >> 6] = incl;
-  __syncthreads();
-  int base = bsum[blockIdx.x];
-  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wsum[w];
-  int run = base + incl - mine;
-  int32_t out[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    out[j] = run;
-    run += (wds[j >> 2] >> (8 * (j & 3))) & 1u;
-  }
-  int4 *dst = reinterpret_cast<int4 *>(pos + t * 16);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) dst[j] = make_int4(out[4 * j], out[4 * j + 1], out[4 * j + 2], out[4 * j + 3]);
-}
-
 struct IngestOut {
   int32_t *user, *anime;
   double *rating;
   int32_t *status, *episodes;
 };
-// stable compaction + scale_ratings
-__global__ __launch_bounds__(256) void k_ing_compact(IngestCols c, int64_t n, const uint8_t *keep, const int32_t *pos,
+// stable compaction + scale_ratings, fused with the last pass of the flag scan: a workgroup owns one scan tile
+// (4 096 rows), turns its flags into output positions in LDS (block base from the spine + in-block exclusive scan)
+// and moves its surviving rows — the 4-byte-per-row position array of a separate scan pass (written and gathered
+// again: 0.9 GB at 109 M rows) never exists.
+__global__ __launch_bounds__(256) void k_ing_compact(IngestCols c, int64_t n, const uint8_t *keep, const int32_t *bsum,
                                                      const unsigned long long *mm, IngestOut o) {
+  __shared__ int wsum[4];
+  __shared__ int32_t posl[kScanTile];
   const double mn = ord2d(mm[0]), mx = ord2d(mm[1]);
   const double span = mx - mn;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    if (!keep[i]) continue;
-    const int32_t p = pos[i];
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const uint4 v = reinterpret_cast<const uint4 *>(keep)[t];  // flags are padded with zeros to whole tiles
+  const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+  const int mine = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+  int incl = mine;  // inclusive scan over the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(incl, d, 64);
+    if (lane_id() >= d) incl += y;
+  }
+  if (lane_id() == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  int run = bsum[blockIdx.x] + incl - mine;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wsum[w];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const uint32_t f = (wds[j >> 2] >> (8 * (j & 3))) & 1u;
+    posl[threadIdx.x * 16 + j] = f ? run : -1;
+    run += f;
+  }
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kScanTile;
+#pragma unroll 4
+  for (int k = 0; k < kScanTile / 256; ++k) {  // coalesced over the tile's rows
+    const int r = k * 256 + threadIdx.x;
+    const int32_t p = posl[r];
+    const int64_t i = base + r;
+    if (p < 0 || i >= n) continue;
     o.user[p] = c.user[i];
     o.anime[p] = c.anime[i];
     o.rating[p] = (c.rating[i] - mn) / span;
@@ -314,6 +315,10 @@ __global__ __launch_bounds__(256) void k_ing_half_columns(const int32_t *anime, 
 }
 
 // ---- Series.unique() encoding: dense index = rank of the id's first appearance ----
+// first[v] = smallest row holding id v (atomicMin, run heads only); the RANK of that row among all first rows is
+// the id's dense index.  The first rows are marked in a bitmap over the rows (n / 8 bytes), a prefix popcount over
+// its words gives every id its rank, and one streaming pass maps the column through the per-id rank table: the
+// column is read twice and the index written once (12 B per row) — no per-row flag, scan or rank arrays.
 __global__ __launch_bounds__(256) void k_enc_first(const int32_t *id, int64_t n, int bound, int32_t *first, int32_t *err) {
   const int lane = lane_id();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -333,26 +338,78 @@ __global__ __launch_bounds__(256) void k_enc_first(const int32_t *id, int64_t n,
       atomicMin(&first[v], (int32_t)i);
   }
 }
-__global__ __launch_bounds__(256) void k_enc_flag(const int32_t *id, int64_t n, int bound, const int32_t *first,
-                                                  uint8_t *isfirst) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int32_t v = id[i];
-    isfirst[i] = (v >= 0 && v < bound && first[v] == (int32_t)i) ? 1 : 0;
-  }
+constexpr int kBitTile = 4096;  // bitmap words per workgroup of the word scan (256 threads x 16 words)
+__global__ __launch_bounds__(256) void k_enc_bits(const int32_t *first, int bound, uint32_t *bits) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= bound) return;
+  const int32_t f = first[v];
+  if (f != 0x7FFFFFFF) atomicOr(&bits[f >> 5], 1u << (f & 31));
 }
-__global__ __launch_bounds__(256) void k_enc_emit(const int32_t *id, int64_t n, int bound, const int32_t *first,
-                                                  const uint8_t *isfirst, const int32_t *rank, int32_t *idx,
+__global__ __launch_bounds__(256) void k_bits_reduce(const uint32_t *bits, int32_t *bsum) {
+  __shared__ int wsum[4];
+  const uint4 *p = reinterpret_cast<const uint4 *>(bits) + ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint4 v = p[k];
+    s += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane_id() == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) bsum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+// wpre[w] = number of set bits in the words before w
+__global__ __launch_bounds__(256) void k_bits_apply(const uint32_t *bits, const int32_t *bsum, int32_t *wpre) {
+  __shared__ int wsum[4];
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t wd[16];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint4 v = reinterpret_cast<const uint4 *>(bits)[t * 4 + k];
+    wd[4 * k] = v.x, wd[4 * k + 1] = v.y, wd[4 * k + 2] = v.z, wd[4 * k + 3] = v.w;
+  }
+  int mine = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) mine += __popc(wd[k]);
+  int incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(incl, d, 64);
+    if (lane_id() >= d) incl += y;
+  }
+  if (lane_id() == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  int run = bsum[blockIdx.x] + incl - mine;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wsum[w];
+  int32_t out[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    out[k] = run;
+    run += __popc(wd[k]);
+  }
+  int4 *dst = reinterpret_cast<int4 *>(wpre + t * 16);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) dst[k] = make_int4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+}
+// first[v] (a row number) -> the id's rank; uniques[rank] = v
+__global__ __launch_bounds__(256) void k_enc_rank(int32_t *first, int bound, const uint32_t *bits, const int32_t *wpre,
                                                   int32_t *uniques) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= bound) return;
+  const int32_t f = first[v];
+  if (f == 0x7FFFFFFF) return;
+  const int32_t rank = wpre[f >> 5] + __popc(bits[f >> 5] & ((1u << (f & 31)) - 1u));
+  first[v] = rank;  // the table now maps id -> dense index
+  uniques[rank] = v;
+}
+__global__ __launch_bounds__(256) void k_enc_emit(const int32_t *id, int64_t n, int bound, const int32_t *rank_of,
+                                                  int32_t *idx) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int32_t v = id[i];
-    if (v < 0 || v >= bound) {
-      idx[i] = -1;
-      continue;
-    }
-    idx[i] = rank[first[v]];
-    if (isfirst[i]) uniques[rank[i]] = v;
+    idx[i] = (v < 0 || v >= bound) ? -1 : rank_of[v];
   }
 }
 
@@ -369,12 +426,12 @@ static inline int grid_for(int64_t n) {
   if (b < 1) b = 1;
   return (int)b;
 }
-// flags (padded, tail zeroed by the caller) -> pos, total
-static int scan_flags(const uint8_t *flags, int64_t n, int32_t *bsum, int32_t *pos, int64_t *total, hipStream_t s) {
+// flags (padded, tail zeroed by the caller) -> exclusive tile bases in bsum, total (the in-tile scan is redone by
+// the consumer, k_ing_compact)
+static int scan_flags(const uint8_t *flags, int64_t n, int32_t *bsum, int64_t *total, hipStream_t s) {
   const int nb = (int)(pad_tile(n) / kScanTile);
   hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, s, flags, bsum);
   hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, bsum, nb, total);
-  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, s, flags, bsum, pos);
   return (int)hipGetLastError();
 }
 
@@ -384,11 +441,11 @@ using namespace anirec;
 
 extern "C" {
 
-// alive | keep (padded byte flags) | pos | bsum | hash table | user counts | anime max | minmax + err
+// alive | keep (padded byte flags) | bsum | hash table | user counts | anime max | minmax + err
 size_t anirec_ingest_workspace_bytes(int64_t n, int32_t user_id_bound, int32_t anime_id_bound) {
   if (n < 1 || n >= ((int64_t)1 << 30) || user_id_bound < 1 || anime_id_bound < 1) return 0;
   const size_t np = pad_tile(n);
-  return 2 * al256(np) + al256(np * 4) + al256(np / kScanTile * 4) + al256((size_t)table_slots(n) * 8) +
+  return 2 * al256(np) + al256(np / kScanTile * 4) + al256((size_t)table_slots(n) * 8) +
          al256((size_t)user_id_bound * 4) + al256((size_t)anime_id_bound * 4) + 256;
 }
 
@@ -411,8 +468,6 @@ int anirec_ingest_preprocess(const int32_t *user_id, const int32_t *anime_id, co
   p += al256(np);
   uint8_t *keep = (uint8_t *)p;
   p += al256(np);
-  int32_t *pos = (int32_t *)p;
-  p += al256(np * 4);
   int32_t *bsum = (int32_t *)p;
   p += al256(np / kScanTile * 4);
   unsigned long long *table = (unsigned long long *)p;
@@ -450,10 +505,10 @@ int anirec_ingest_preprocess(const int32_t *user_id, const int32_t *anime_id, co
     hipLaunchKernelGGL(k_ing_minmax, dim3(g > 2048 ? 2048 : g), dim3(256), 0, s, rating, n, keep, mm);
   }
   ANIREC_HIP_CHECK(hipGetLastError());
-  int rc = scan_flags(keep, n, bsum, pos, n_out, s);
+  int rc = scan_flags(keep, n, bsum, n_out, s);
   if (rc) return rc;
   const IngestOut o{out_user_id, out_anime_id, out_rating, out_status, out_episodes};
-  hipLaunchKernelGGL(k_ing_compact, dim3(g), dim3(256), 0, s, c, n, keep, pos, mm, o);
+  hipLaunchKernelGGL(k_ing_compact, dim3((unsigned)(np / kScanTile)), dim3(256), 0, s, c, n, keep, bsum, mm, o);
   return (int)hipGetLastError();
 }
 
@@ -468,18 +523,20 @@ int anirec_ingest_half_columns(const int32_t *out_anime_id, const int64_t *n_out
   // same carve as anirec_ingest_preprocess: the per-anime maxima sit behind the user counts
   const size_t np = pad_tile(n);
   const char *p = (const char *)workspace;
-  p += 2 * al256(np) + al256(np * 4) + al256(np / kScanTile * 4) + al256((size_t)table_slots(n) * 8) +
+  p += 2 * al256(np) + al256(np / kScanTile * 4) + al256((size_t)table_slots(n) * 8) +
        al256((size_t)opts->user_id_bound * 4);
   hipLaunchKernelGGL(k_ing_half_columns, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out_anime_id, n_out,
                      (const int32_t *)p, out_max_eps, out_half_eps);
   return (int)hipGetLastError();
 }
 
-// isfirst (padded) | rank | bsum | first-appearance table
+// first-appearance / rank table [id_bound] | bitmap over the rows (padded to whole word tiles) | word prefix | bsum
+static inline size_t bit_words(int64_t n) { return (((size_t)n + 31) / 32 + kBitTile - 1) / kBitTile * kBitTile; }
+
 size_t anirec_ingest_encode_workspace_bytes(int64_t n, int32_t id_bound) {
   if (n < 1 || n >= ((int64_t)1 << 30) || id_bound < 1) return 0;
-  const size_t np = pad_tile(n);
-  return al256(np) + al256(np * 4) + al256(np / kScanTile * 4) + al256((size_t)id_bound * 4) + 256;
+  const size_t nw = bit_words(n);
+  return al256((size_t)id_bound * 4) + 2 * al256(nw * 4) + al256(nw / kBitTile * 4) + 256;
 }
 
 int anirec_ingest_encode(const int32_t *id, int64_t n, int32_t id_bound, int32_t *out_index, int32_t *out_uniques,
@@ -489,26 +546,28 @@ int anirec_ingest_encode(const int32_t *id, int64_t n, int32_t id_bound, int32_t
   if (n < 1 || n >= ((int64_t)1 << 30) || id_bound < 1) return ANIREC_EINVAL;
   if (workspace_bytes < anirec_ingest_encode_workspace_bytes(n, id_bound)) return ANIREC_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  const size_t np = pad_tile(n);
+  const size_t nw = bit_words(n);
   char *p = (char *)workspace;
-  uint8_t *isfirst = (uint8_t *)p;
-  p += al256(np);
-  int32_t *rank = (int32_t *)p;
-  p += al256(np * 4);
-  int32_t *bsum = (int32_t *)p;
-  p += al256(np / kScanTile * 4);
   int32_t *first = (int32_t *)p;
+  p += al256((size_t)id_bound * 4);
+  uint32_t *bits = (uint32_t *)p;
+  p += al256(nw * 4);
+  int32_t *wpre = (int32_t *)p;
+  p += al256(nw * 4);
+  int32_t *bsum = (int32_t *)p;
   const int g = grid_for(n);
+  const int gb = (id_bound + 255) / 256;
+  const int nb = (int)(nw / kBitTile);
   ANIREC_HIP_CHECK(hipMemsetAsync(err_flag, 0, 4, s));
-  ANIREC_HIP_CHECK(hipMemsetAsync(isfirst + n, 0, np - (size_t)n, s));
+  ANIREC_HIP_CHECK(hipMemsetAsync(bits, 0, nw * 4, s));
   ANIREC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)first, 0x7FFFFFFF, (size_t)id_bound, s));
   hipLaunchKernelGGL(k_enc_first, dim3(g), dim3(256), 0, s, id, n, id_bound, first, err_flag);
-  hipLaunchKernelGGL(k_enc_flag, dim3(g), dim3(256), 0, s, id, n, id_bound, first, isfirst);
-  ANIREC_HIP_CHECK(hipGetLastError());
-  int rc = scan_flags(isfirst, n, bsum, rank, n_unique, s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_enc_emit, dim3(g), dim3(256), 0, s, id, n, id_bound, first, isfirst, rank, out_index,
-                     out_uniques);
+  hipLaunchKernelGGL(k_enc_bits, dim3(gb), dim3(256), 0, s, first, id_bound, bits);
+  hipLaunchKernelGGL(k_bits_reduce, dim3(nb), dim3(256), 0, s, bits, bsum);
+  hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, bsum, nb, n_unique);
+  hipLaunchKernelGGL(k_bits_apply, dim3(nb), dim3(256), 0, s, bits, bsum, wpre);
+  hipLaunchKernelGGL(k_enc_rank, dim3(gb), dim3(256), 0, s, first, id_bound, bits, wpre, out_uniques);
+  hipLaunchKernelGGL(k_enc_emit, dim3(g), dim3(256), 0, s, id, n, id_bound, first, out_index);
   return (int)hipGetLastError();
 }
 

@@ -217,7 +217,7 @@ def git_blob_hash(path):
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
-def pmc_traffic(name, kernels=None, source=None):
+def pmc_traffic(name, kernels=None, source=None, calls=None):
     """HBM bytes from the committed PMC passes (profiles/<round>_pmc_traffic_<name>.json): per-launch mean of one
     kernel, or the sum over the listed kernels of (mean bytes x launches per call).  The JSON records the git blob
     hash of every csrc/*.hip at collection time; if `source` (the file holding the kernel) has changed since, the
@@ -231,6 +231,8 @@ def pmc_traffic(name, kernels=None, source=None):
         d = rec["kernels"]
         if isinstance(kernels, str):
             return d[kernels]["total_bytes_per_launch"]
+        if calls:      # all launches of the listed kernels in one call of the op (the profiled script makes `calls` calls)
+            return sum(d[k]["total_bytes_all_launches"] for k in kernels) / calls
         return sum(d[k]["total_bytes_per_launch"] * n for k, n in kernels.items())
     except (OSError, KeyError, ValueError, TypeError):
         return None
@@ -263,7 +265,11 @@ def _cosine_leg(W, nq, k, cpu_baseline, reps=3, slice_note=None, traffic_name=No
         cand_ms += ms
         cand_launches += nl
     tfk = flops / (cand_ms * 1e-3) / 1e12
-    traffic = pmc_traffic(traffic_name, {"k_cand": 1}, source="anirec_topk_mfma.hip") if traffic_name else None
+    # HBM bytes of all k_cand launches of ONE call on the profiled 65 536-query slice (scripts/time_topk.py makes 2
+    # calls), scaled to this leg's query count
+    traffic = pmc_traffic(traffic_name, ["k_cand<0, 8, false>"], source="anirec_topk_mfma.hip", calls=2) if traffic_name else None
+    if traffic is not None:
+        traffic *= nq / 65536.0
     rec = {"value": nq / dt, "unit": "queries/s", "ms": dt * 1e3, "k": k, "n_keys": n, "n_queries": nq,
            "fallback_rows": int(nfb), "pipeline_tflops": flops / dt / 1e12,
            "roofline": {"kernel": "k_cand (v_mfma_f32_16x16x32_f16 scores + fused candidate filter), "
@@ -302,7 +308,7 @@ def run_cosine_topk(cpu_baseline=True, trained=None):
                                                     traffic_name="cosine_topk_k100")
     out["anime_18k_allpairs_top10"] = _cosine_leg(Wa, 18_000, 10, False)
     out["users_350k_allpairs_top10"] = _cosine_leg(Wu, 350_000, 10, False, reps=2)
-    out["users_350k_keys_65536q_top100"] = _cosine_leg(Wu, 65_536, 100, False,
+    out["users_350k_keys_65536q_top100"] = _cosine_leg(Wu, 65_536, 100, False, traffic_name="cosine_topk_k100",
                                                        slice_note="one 65 536-query slice of the all-pairs job")
     del Wu, Wa
     torch.cuda.empty_cache()
@@ -603,7 +609,7 @@ def run_predict_grid(cpu_baseline=True):
            "roofline": {"kernel": "k_predict_mfma2 (split-f16 MFMA, anime as the row operand: 16-B non-temporal row-quad "
                                   "stores, sigmoid + stores of a tile under the MFMAs of the next)", "bound": "hbm",
                         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                        "traffic": pmc_traffic("pgrid", "k_predict_mfma2", source="anirec_predict_mfma.hip")}}
+                        "traffic": pmc_traffic("pgrid", "k_predict_mfma2<0>", source="anirec_predict_mfma.hip")}}
     if cpu_baseline:
         from oracle import c_oracle
         Un, An = U[:4096].cpu().numpy(), A.cpu().numpy()
