@@ -8,9 +8,10 @@
 //   neural_network/neural_network.py:41-60 get_df   (id -> position in Series.unique(): order of
 //                                                    first appearance)
 // which the reference does with pandas (dict lookups and Python loops per row).  All of it is
-// HBM-bound integer / byte work: flag passes, one open-addressing hash table for the duplicate rows,
-// direct-index tables for the per-user / per-anime aggregates, and a 3-pass flag scan that turns
-// flags into stable (order-preserving) output positions.  Results are bit-identical to pandas:
+// HBM-bound integer / byte work: one front pass over the five columns (row filters, duplicate rows through an
+// LDS hash table per chunk of rows, per-user counts), direct-index tables for the per-user / per-anime
+// aggregates, and a flag scan fused into the compaction that turns flags into stable (order-preserving)
+// output positions.  Results are bit-identical to pandas:
 // the surviving rows keep their order, duplicates keep their FIRST occurrence, indices follow first
 // appearance, and the scaling is the same IEEE double expression.
 #include <hip/hip_runtime.h>
@@ -62,27 +63,318 @@ __host__ __device__ inline double ord2d(unsigned long long o) {
   memcpy(&d, &b, 8);
   return d;
 }
-// dropna + the two row-local filters (they commute with drop_duplicates: duplicates share their fate)
-__global__ __launch_bounds__(256) void k_ing_alive(IngestCols c, int64_t n, int drop_unwatched, int drop_plan,
-                                                   int user_bound, int anime_bound, uint8_t *alive,
-                                                   uint8_t *keep, int32_t *err) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int32_t u = c.user[i], a = c.anime[i], s = c.status[i], e = c.episodes[i];
-    const double r = c.rating[i];
-    bool ok = u != ANIREC_NULL_I32 && a != ANIREC_NULL_I32 && s != ANIREC_NULL_I32 && e != ANIREC_NULL_I32 &&
-              r == r;
-    if (ok && (u < 0 || u >= user_bound || a < 0 || a >= anime_bound)) {
-      *err = 1;  // id outside the direct-index tables: the host reports ANIREC_EINVAL
-      ok = false;
+// ---- the front pass -------------------------------------------------------------------------------------------
+// dropna, the two row-local filters, drop_duplicates(keep='first'), value_counts(user_id) and the num_reviews
+// filter in ONE read of the five columns.
+//
+// Identical rows share their user, so duplicates can only meet inside the rows of one user.  The table is cut into
+// chunks of kChunk consecutive rows, one workgroup each; k_ing_span first records every user's first and last row.
+// A user whose rows all lie inside one chunk is LOCAL to it: its duplicates are found in an LDS hash table of the
+// chunk, its rating count is complete when the chunk is done (counted in LDS, at the slot of the user's first
+// row), so the num_reviews filter (and min / max of the surviving ratings) is settled before the workgroup leaves.
+// The raw animelist is grouped by user, so the only non-local rows are those of the users whose block of rows
+// straddles a chunk boundary (a few % of the table): they are appended to a list and go through the global hash
+// table (k_nl_*), which is sized and cleared for the list, not for the table.  Nothing assumes the grouping: a
+// table in random order just has every row on the list.
+constexpr int kChunk = 8192;                  // rows per workgroup; two workgroups share a CU's LDS
+constexpr int kFrontThreads = 512;
+constexpr int kQuads = kChunk / (4 * kFrontThreads);  // a lane owns 4 consecutive rows in each of kQuads passes
+constexpr int kLdsSlots = 2 * kChunk;         // 4-byte slots {18-bit tag | 13-bit row in chunk}: 64 KB
+constexpr uint32_t kLdsEmpty = 0xFFFFFFFFu;   // no entry has it: the top tag bit is always 0
+constexpr uint32_t kRowMask = kChunk - 1;
+static_assert(kChunk % kScanTile == 0 && (kChunk & (kChunk - 1)) == 0, "chunk = whole scan tiles, power of two");
+static_assert(kQuads * 4 * kFrontThreads == kChunk && kChunk / kScanTile == 2 && kQuads % 2 == 0, "row mapping");
+
+__device__ __forceinline__ int4 ld4(const int32_t *p, int64_t i, int64_t n, int32_t fill) {
+  if (i + 3 < n) return *reinterpret_cast<const int4 *>(p + i);
+  return make_int4(i < n ? p[i] : fill, i + 1 < n ? p[i + 1] : fill, i + 2 < n ? p[i + 2] : fill, fill);
+}
+
+// first / last row of every user (all rows with a valid id, whatever their other columns hold).  A lane reads 4
+// consecutive rows; only the first row of a run of equal ids updates the first-row table and only the last row
+// of a run the last-row table, and both read before they update (a stale read only costs a redundant atomic).
+constexpr int kSpanIters = 4;
+__global__ __launch_bounds__(256) void k_ing_span(const int32_t *user, int64_t n, int bound, int32_t *ufirst,
+                                                  int32_t *ulast) {
+  const int lane = lane_id();
+  int4 q[kSpanIters];
+  int64_t i0[kSpanIters];
+#pragma unroll
+  for (int k = 0; k < kSpanIters; ++k) {
+    i0[k] = (((int64_t)blockIdx.x * kSpanIters + k) * 256 + threadIdx.x) * 4;
+    q[k] = ld4(user, i0[k], n, -1);
+  }
+#pragma unroll
+  for (int k = 0; k < kSpanIters; ++k) {
+    int32_t v[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (v[j] < 0 || v[j] >= bound) v[j] = -1;
+    const int32_t left = __shfl_up(v[3], 1, 64), right = __shfl_down(v[0], 1, 64);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (v[j] < 0) continue;
+      const int32_t i = (int32_t)(i0[k] + j);
+      const bool head = j ? v[j] != v[j - 1] : (lane == 0 || v[0] != left);
+      const bool tail = j < 3 ? v[j] != v[j + 1] : (lane == 63 || v[3] != right);
+      if (head && ufirst[v[j]] > i) atomicMin(&ufirst[v[j]], i);
+      if (tail && ulast[v[j]] < i) atomicMax(&ulast[v[j]], i);
     }
-    if (ok && drop_unwatched && e == 0) ok = false;
-    if (ok && drop_plan && s == 6) ok = false;
-    alive[i] = ok ? 1 : 0;
-    keep[i] = ok ? 1 : 0;  // k_ing_insert clears the later members of every class of identical rows
   }
 }
 
+struct RowVals {
+  int32_t u, a, s, e;
+  double r;
+};
+__device__ __forceinline__ uint64_t row_hash(const RowVals &v) {
+  uint64_t h = mix64(((uint64_t)(uint32_t)v.u << 32) | (uint32_t)v.a);
+  h = mix64(h ^ rating_bits(v.r));
+  h = mix64(h ^ (((uint64_t)(uint32_t)v.s << 32) | (uint32_t)v.e));
+  return h;
+}
+__device__ __forceinline__ bool row_eq(const IngestCols &c, const RowVals &v, int64_t j) {
+  return v.u == c.user[j] && v.a == c.anime[j] && v.s == c.status[j] && v.e == c.episodes[j] &&
+         rating_bits(v.r) == rating_bits(c.rating[j]);
+}
+
+struct FrontArgs {
+  IngestCols c;
+  int64_t n;
+  int drop_unwatched, drop_plan, user_bound, anime_bound, num_reviews, n_tiles;
+  const int32_t *ufirst, *ulast;
+  uint8_t *keep;       // [chunks * kChunk]
+  int32_t *tile_cnt;   // [n_tiles] surviving rows per scan tile (the list kernels subtract what they drop later)
+  int32_t *nl_list;    // rows of non-local users that passed the row filters
+  int32_t *nl_count;   // zeroed
+  unsigned long long *mm;
+  int32_t *err;
+};
+
+// per-row state carried from phase A to phase C: bit 15 = passed the row filters, bit 14 = local user,
+// bits 0..12 = the user's first row in the chunk (the slot of its counter)
+constexpr uint32_t kOk = 0x8000u, kLocal = 0x4000u;
+
+template <bool kMinMax>
+__global__ __launch_bounds__(kFrontThreads, 2) void k_ing_front(FrontArgs a) {
+  __shared__ uint32_t tab[kLdsSlots];  // phase A: the hash table; afterwards [0, kChunk): the users' counters
+  __shared__ uint8_t keepl[kChunk];
+  __shared__ int32_t tile_l[2];
+  __shared__ int32_t nl_total, nl_base, nl_fill;
+  __shared__ unsigned long long red[2][kFrontThreads / 64];
+  const int tid = threadIdx.x, lane = lane_id();
+  const IngestCols &c = a.c;
+  const int64_t base = (int64_t)blockIdx.x * kChunk;
+
+  {
+    uint4 *t4 = reinterpret_cast<uint4 *>(tab);
+    for (int k = tid; k < kLdsSlots / 4; k += kFrontThreads) t4[k] = make_uint4(kLdsEmpty, kLdsEmpty, kLdsEmpty, kLdsEmpty);
+    uint4 *k4 = reinterpret_cast<uint4 *>(keepl);
+    for (int k = tid; k < kChunk / 16; k += kFrontThreads) k4[k] = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+    if (tid < 2) tile_l[tid] = 0;
+    if (tid == 0) nl_total = 0, nl_fill = 0;
+  }
+  __syncthreads();
+
+  // phase A: row filters; rows of local users into the LDS table, the later members of a class lose their flag
+  uint16_t meta[kQuads][4];
+  double rat[kMinMax ? kQuads : 1][4];
+  bool bad = false;
+#pragma unroll
+  for (int h = 0; h < kQuads; h += 2) {  // two quads of loads in flight
+    int4 U[2], A[2], S[2], E[2];
+    double R[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int64_t i = base + ((h + b) * kFrontThreads + tid) * 4;
+      U[b] = ld4(c.user, i, a.n, ANIREC_NULL_I32);
+      A[b] = ld4(c.anime, i, a.n, 0);
+      S[b] = ld4(c.status, i, a.n, 0);
+      E[b] = ld4(c.episodes, i, a.n, 0);
+      if (i + 3 < a.n) {
+        const double2 r0 = *reinterpret_cast<const double2 *>(c.rating + i);
+        const double2 r1 = *reinterpret_cast<const double2 *>(c.rating + i + 2);
+        R[b][0] = r0.x, R[b][1] = r0.y, R[b][2] = r1.x, R[b][3] = r1.y;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) R[b][j] = i + j < a.n ? c.rating[i + j] : 0.0;
+      }
+    }
+    int32_t F[2][4], L[2][4];
+    bool ok[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int32_t u[4] = {U[b].x, U[b].y, U[b].z, U[b].w}, an[4] = {A[b].x, A[b].y, A[b].z, A[b].w};
+      const int32_t st[4] = {S[b].x, S[b].y, S[b].z, S[b].w}, ep[4] = {E[b].x, E[b].y, E[b].z, E[b].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bool o = u[j] != ANIREC_NULL_I32 && an[j] != ANIREC_NULL_I32 && st[j] != ANIREC_NULL_I32 &&
+                 ep[j] != ANIREC_NULL_I32 && R[b][j] == R[b][j];
+        if (o && (u[j] < 0 || u[j] >= a.user_bound || an[j] < 0 || an[j] >= a.anime_bound)) {
+          bad = true;  // id outside the direct-index tables: the host reports ANIREC_EINVAL
+          o = false;
+        }
+        if (o && a.drop_unwatched && ep[j] == 0) o = false;
+        if (o && a.drop_plan && st[j] == 6) o = false;
+        ok[b][j] = o;
+        F[b][j] = a.ufirst[o ? u[j] : 0];
+        L[b][j] = a.ulast[o ? u[j] : 0];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int32_t u[4] = {U[b].x, U[b].y, U[b].z, U[b].w}, an[4] = {A[b].x, A[b].y, A[b].z, A[b].w};
+      const int32_t st[4] = {S[b].x, S[b].y, S[b].z, S[b].w}, ep[4] = {E[b].x, E[b].y, E[b].z, E[b].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ridx = ((h + b) * kFrontThreads + tid) * 4 + j;
+        if (kMinMax) rat[h + b][j] = R[b][j];
+        meta[h + b][j] = 0;
+        if (!ok[b][j]) continue;
+        meta[h + b][j] = kOk;
+        if ((int64_t)F[b][j] < base || (int64_t)L[b][j] >= base + kChunk) continue;  // non-local: the list
+        meta[h + b][j] = (uint16_t)(kOk | kLocal | (uint32_t)(F[b][j] - base));
+        const RowVals v{u[j], an[j], st[j], ep[j], R[b][j]};
+        const uint64_t hh = row_hash(v);
+        const uint32_t entry = ((uint32_t)(hh >> 32) & 0x7FFFE000u) | (uint32_t)ridx;
+        uint32_t s = (uint32_t)hh & (kLdsSlots - 1);
+        for (;;) {
+          const uint32_t old = atomicCAS(&tab[s], kLdsEmpty, entry);
+          if (old == kLdsEmpty) break;
+          if (((old ^ entry) & ~kRowMask) == 0 && row_eq(c, v, base + (old & kRowMask))) {
+            // same tag: the minimum entry is the minimum row; prev is a member of the same class (see k_nl_insert)
+            const uint32_t prev = atomicMin(&tab[s], entry);
+            keepl[prev > entry ? (prev & kRowMask) : (uint32_t)ridx] = 0;
+            break;
+          }
+          s = (s + 1) & (kLdsSlots - 1);
+        }
+      }
+    }
+  }
+  if (bad) *a.err = 1;
+  __syncthreads();
+  for (int k = tid; k < kChunk / 4; k += kFrontThreads) reinterpret_cast<uint4 *>(tab)[k] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+
+  // phase B: value_counts of the local users over the rows that are left, one LDS atomic per run of equal users
+  // among a lane's 4 consecutive rows.  Every row of a local user is in this chunk: after the barrier the counts
+  // are final.
+  int nl = 0;
+#pragma unroll
+  for (int q = 0; q < kQuads; ++q) {
+    const uint32_t kb = *reinterpret_cast<const uint32_t *>(&keepl[(q * kFrontThreads + tid) * 4]);
+    int run = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t m = meta[q][j];
+      if (!((kb >> (8 * j)) & 1u)) m = 0;  // lost to an earlier equal row
+      meta[q][j] = (uint16_t)m;
+      nl += (m & (kOk | kLocal)) == kOk;
+      const bool cnt = (m & kLocal) != 0;
+      const bool same_next = j < 3 && cnt && ((kb >> (8 * (j + 1))) & 1u) && meta[q][j + 1] == m;
+      run += cnt;
+      if (cnt && !same_next) {
+        atomicAdd(&tab[m & kRowMask], (uint32_t)run);
+        run = 0;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) nl += __shfl_xor(nl, o, 64);
+  if (lane == 0 && nl) atomicAdd(&nl_total, nl);
+  __syncthreads();
+  if (tid == 0 && nl_total) nl_base = atomicAdd(a.nl_count, nl_total);
+  __syncthreads();
+
+  // phase C: the num_reviews filter for the local rows, the flags, the list of non-local rows
+  unsigned long long lo = ~0ULL, hi = 0ULL;
+  int tcnt[2] = {0, 0};
+#pragma unroll
+  for (int q = 0; q < kQuads; ++q) {
+    const int64_t i = base + (q * kFrontThreads + tid) * 4;
+    uint32_t kb = 0;
+    int nlq = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t m = meta[q][j];
+      bool kept = (m & kOk) != 0;
+      if (m & kLocal) {
+        if ((int32_t)tab[m & kRowMask] < a.num_reviews) {
+          kept = false;
+        } else if (kMinMax) {
+          const unsigned long long o = d2ord(rat[q][j]);
+          lo = o < lo ? o : lo;
+          hi = o > hi ? o : hi;
+        }
+      } else {
+        nlq += kept;
+      }
+      kb |= (uint32_t)kept << (8 * j);
+      tcnt[q / (kQuads / 2)] += kept;
+    }
+    *reinterpret_cast<uint32_t *>(&a.keep[i]) = kb;
+    if (__ballot(nlq != 0)) {  // rare: the rows of a user that straddles the chunk boundary
+      int incl = nlq;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += y;
+      }
+      int off = 0;
+      if (lane == 63) off = atomicAdd(&nl_fill, incl);
+      off = __shfl(off, 63, 64) + nl_base + incl - nlq;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if ((meta[q][j] & (kOk | kLocal)) == kOk) a.nl_list[off++] = (int32_t)(i + j);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int v = tcnt[t];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0 && v) atomicAdd(&tile_l[t], v);
+  }
+  if (kMinMax) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const unsigned long long l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+      lo = l2 < lo ? l2 : lo;
+      hi = h2 > hi ? h2 : hi;
+    }
+    if (lane == 0) {
+      red[0][tid >> 6] = lo;
+      red[1][tid >> 6] = hi;
+    }
+  }
+  __syncthreads();
+  if (tid < 2) {
+    const int t = blockIdx.x * 2 + tid;
+    if (t < a.n_tiles) a.tile_cnt[t] = tile_l[tid];
+  }
+  if (kMinMax && tid == 0) {  // one pair of atomics per workgroup
+    for (int w = 1; w < kFrontThreads / 64; ++w) {
+      lo = red[0][w] < lo ? red[0][w] : lo;
+      hi = red[1][w] > hi ? red[1][w] : hi;
+    }
+    if (lo <= hi) {
+      atomicMin(&a.mm[0], lo);
+      atomicMax(&a.mm[1], hi);
+    }
+  }
+}
+
+// ---- the rows of non-local users (the list) ----
+__device__ __forceinline__ uint32_t nl_slots(int32_t count) {  // power of two >= 2 * count
+  uint32_t s = 4096;
+  while (s < (uint32_t)count * 2u) s <<= 1;
+  return s;
+}
+__global__ __launch_bounds__(256) void k_nl_clear(unsigned long long *table, const int32_t *nl_count) {
+  const uint32_t slots = nl_slots(*nl_count);
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < slots; s += gridDim.x * blockDim.x) table[s] = ~0ULL;
+}
 // drop_duplicates(keep='first'): every class of identical rows owns one table slot that ends up
 // holding the SMALLEST row index of the class, whatever the insertion order: a row that meets an equal
 // row in its slot does atomicMin(slot, i); the larger of (i, previous owner) has lost and its keep
@@ -90,11 +382,12 @@ __global__ __launch_bounds__(256) void k_ing_alive(IngestCols c, int64_t n, int 
 // the table is needed afterwards.
 // A slot is {upper 32 hash bits, row index}: a probe that lands on another class is rejected by the
 // tag without touching that row's five columns (five random sectors).
-__global__ __launch_bounds__(256) void k_ing_insert(IngestCols c, int64_t n, const uint8_t *alive,
-                                                    unsigned long long *table, uint32_t mask, uint8_t *keep) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    if (!alive[i]) continue;
+__global__ __launch_bounds__(256) void k_nl_insert(IngestCols c, const int32_t *nl_list, const int32_t *nl_count,
+                                                   unsigned long long *table, uint8_t *keep, int32_t *tile_cnt) {
+  const int32_t count = *nl_count;
+  const uint32_t mask = nl_slots(count) - 1;
+  for (int32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
+    const int64_t i = nl_list[t];
     const uint64_t h = row_hash(c, i);
     const unsigned long long entry = (h & 0xFFFFFFFF00000000ULL) | (uint32_t)i;
     uint32_t s = (uint32_t)h & mask;
@@ -104,44 +397,49 @@ __global__ __launch_bounds__(256) void k_ing_insert(IngestCols c, int64_t n, con
       if ((old >> 32) == (entry >> 32) && row_eq(c, i, (int64_t)(uint32_t)old)) {
         // same tag: the 64-bit minimum is the minimum row index; prev is a member of the same class
         const unsigned long long prev = atomicMin(&table[s], entry);
-        keep[prev > entry ? (uint32_t)prev : (uint32_t)i] = 0;
+        const uint32_t loser = prev > entry ? (uint32_t)prev : (uint32_t)i;
+        keep[loser] = 0;
+        atomicSub(&tile_cnt[loser / kScanTile], 1);
         break;
       }
       s = (s + 1) & mask;
     }
   }
 }
-
-// value_counts() of user_id over the surviving rows.  The raw table is grouped by user (ascending
-// blocks of user_id), so consecutive rows mostly share their user: a wave adds one atomic per RUN of
-// equal ids among its 64 consecutive rows instead of one per row.
-__global__ __launch_bounds__(256) void k_ing_count(const int32_t *id, int64_t n, const uint8_t *keep, int32_t *cnt) {
+// value_counts of the non-local users (consecutive list entries mostly share their user: one atomic per run)
+__global__ __launch_bounds__(256) void k_nl_count(const int32_t *user, const int32_t *nl_list, const int32_t *nl_count,
+                                                  const uint8_t *keep, int32_t *cnt) {
   const int lane = lane_id();
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int64_t n_round = (n + 63) / 64 * 64;  // whole waves stay converged for the shuffles
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
-    const int32_t key = (i < n && keep[i]) ? id[i] : -1;
+  const int32_t count = *nl_count;
+  const int32_t n_round = (count + 63) / 64 * 64;
+  for (int32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_round; t += gridDim.x * blockDim.x) {
+    int32_t key = -1;
+    if (t < count) {
+      const int32_t i = nl_list[t];
+      if (keep[i]) key = user[i];
+    }
     const int32_t left = __shfl_up(key, 1, 64);
     const bool head = lane == 0 || key != left;
     const unsigned long long heads = __ballot(head);
     if (head && key >= 0) {
       const unsigned long long later = lane == 63 ? 0ULL : heads >> (lane + 1);
-      const int len = later ? __ffsll((long long)later) : 64 - lane;
-      atomicAdd(&cnt[key], len);
+      atomicAdd(&cnt[key], later ? __ffsll((long long)later) : 64 - lane);
     }
   }
 }
 // the num_reviews filter; when it is the last filter it also reduces min / max of the ratings
 template <bool kMinMax>
-__global__ __launch_bounds__(256) void k_ing_user_filter(const int32_t *user, const double *rating, int64_t n,
-                                                         const int32_t *cnt, int num_reviews, uint8_t *keep,
-                                                         unsigned long long *mm) {
+__global__ __launch_bounds__(256) void k_nl_filter(const int32_t *user, const double *rating, const int32_t *nl_list,
+                                                   const int32_t *nl_count, const int32_t *cnt, int num_reviews,
+                                                   uint8_t *keep, int32_t *tile_cnt, unsigned long long *mm) {
   unsigned long long lo = ~0ULL, hi = 0ULL;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  const int32_t count = *nl_count;
+  for (int32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
+    const int32_t i = nl_list[t];
     if (!keep[i]) continue;
     if (cnt[user[i]] < num_reviews) {
       keep[i] = 0;
+      atomicSub(&tile_cnt[i / kScanTile], 1);
       continue;
     }
     if (kMinMax) {
@@ -227,24 +525,23 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint8_t *flags, int32
   if (threadIdx.x == 0) bsum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 __global__ __launch_bounds__(1024) void k_scan_spine(int32_t *bsum, int nb, int64_t *total) {
-  __shared__ long long part[1024];
+  __shared__ long long part[16];
   const int per = (nb + 1023) / 1024;
   const int b0 = threadIdx.x * per, b1 = min(nb, b0 + per);
   long long s = 0;
   for (int b = b0; b < b1; ++b) s += bsum[b];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    long long run = 0;
-    for (int t = 0; t < 1024; ++t) {
-      const long long x = part[t];
-      part[t] = run;
-      run += x;
-    }
-    *total = run;
+  long long incl = s;  // inclusive scan over the wave, then over the 16 wave totals
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const long long y = __shfl_up(incl, d, 64);
+    if (lane_id() >= d) incl += y;
   }
+  if (lane_id() == 63) part[threadIdx.x >> 6] = incl;
   __syncthreads();
-  int run = (int)part[threadIdx.x];
+  long long before = 0;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += part[w];
+  if (threadIdx.x == 1023) *total = before + incl;
+  int run = (int)(before + incl - s);
   for (int b = b0; b < b1; ++b) {
     const int x = bsum[b];
     bsum[b] = run;
@@ -319,24 +616,38 @@ __global__ __launch_bounds__(256) void k_ing_half_columns(const int32_t *anime, 
 // the id's dense index.  The first rows are marked in a bitmap over the rows (n / 8 bytes), a prefix popcount over
 // its words gives every id its rank, and one streaming pass maps the column through the per-id rank table: the
 // column is read twice and the index written once (12 B per row) — no per-row flag, scan or rank arrays.
+constexpr int kEncIters = 4;  // a lane reads kEncIters x 4 consecutive rows, all loads issued before the first use
 __global__ __launch_bounds__(256) void k_enc_first(const int32_t *id, int64_t n, int bound, int32_t *first, int32_t *err) {
   const int lane = lane_id();
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int64_t n_round = (n + 63) / 64 * 64;  // whole waves stay converged for the shuffle
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
-    int32_t v = i < n ? id[i] : -1;
-    if (i < n && (v < 0 || v >= bound)) {
-      *err = 1;
-      v = -1;
-    }
-    // A table grouped by user presents runs of equal ids to a wave: only the first lane of a run (the
-    // smallest row index of the run) goes to memory.  It reads first (at L2, where the atomics land: an
-    // L1 line would stay stale), so that after its first few rows an id costs no atomic at all.
-    const int32_t left = __shfl_up(v, 1, 64);
-    const bool head = lane == 0 || v != left;
-    if (head && v >= 0 && __hip_atomic_load(&first[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (int32_t)i)
-      atomicMin(&first[v], (int32_t)i);
+  int4 q[kEncIters];
+  int64_t i0[kEncIters];
+#pragma unroll
+  for (int k = 0; k < kEncIters; ++k) {
+    i0[k] = (((int64_t)blockIdx.x * kEncIters + k) * 256 + threadIdx.x) * 4;
+    q[k] = ld4(id, i0[k], n, -1);
   }
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < kEncIters; ++k) {
+    int32_t v[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (v[j] < 0 || v[j] >= bound) {
+        bad |= i0[k] + j < n;
+        v[j] = -1;
+      }
+    // A table grouped by user presents runs of equal ids: only the first row of a run goes to memory, and it
+    // reads before it updates (a stale read only costs a redundant atomic), so that after its first few rows an
+    // id costs no atomic at all.
+    const int32_t left = __shfl_up(v[3], 1, 64);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool head = j ? v[j] != v[j - 1] : (lane == 0 || v[0] != left);
+      const int32_t i = (int32_t)(i0[k] + j);
+      if (head && v[j] >= 0 && first[v[j]] > i) atomicMin(&first[v[j]], i);
+    }
+  }
+  if (bad) *err = 1;
 }
 constexpr int kBitTile = 4096;  // bitmap words per workgroup of the word scan (256 threads x 16 words)
 __global__ __launch_bounds__(256) void k_enc_bits(const int32_t *first, int bound, uint32_t *bits) {
@@ -406,47 +717,93 @@ __global__ __launch_bounds__(256) void k_enc_rank(int32_t *first, int bound, con
 }
 __global__ __launch_bounds__(256) void k_enc_emit(const int32_t *id, int64_t n, int bound, const int32_t *rank_of,
                                                   int32_t *idx) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int32_t v = id[i];
-    idx[i] = (v < 0 || v >= bound) ? -1 : rank_of[v];
+  int4 q[kEncIters];
+  int64_t i0[kEncIters];
+#pragma unroll
+  for (int k = 0; k < kEncIters; ++k) {
+    i0[k] = (((int64_t)blockIdx.x * kEncIters + k) * 256 + threadIdx.x) * 4;
+    q[k] = ld4(id, i0[k], n, -1);
+  }
+#pragma unroll
+  for (int k = 0; k < kEncIters; ++k) {
+    const int32_t v[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+    int32_t r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = (v[j] < 0 || v[j] >= bound) ? -1 : rank_of[v[j]];
+    if (i0[k] + 3 < n) {
+      *reinterpret_cast<int4 *>(idx + i0[k]) = make_int4(r[0], r[1], r[2], r[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i0[k] + j < n) idx[i0[k] + j] = r[j];
+    }
   }
 }
 
 static inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
-static inline size_t pad_tile(int64_t n) { return ((size_t)n + kScanTile - 1) / kScanTile * kScanTile; }
+static inline size_t pad_tile(int64_t n) { return ((size_t)n + kChunk - 1) / kChunk * kChunk; }  // whole chunks
 static inline uint32_t table_slots(int64_t n) {
-  uint64_t s = 1024;
+  uint64_t s = 4096;  // = nl_slots(n), the list's worst case
   while (s < (uint64_t)n * 2) s <<= 1;
   return (uint32_t)s;
 }
+// workgroups of 256 lanes x iters quads of 4 rows
+static inline unsigned quad_grid(int64_t n, int iters) { return (unsigned)((n + 1024 * iters - 1) / (1024 * iters)); }
+static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 static inline int grid_for(int64_t n) {
   int64_t b = (n + 255) / 256;
   if (b > 16384) b = 16384;
   if (b < 1) b = 1;
   return (int)b;
 }
-// flags (padded, tail zeroed by the caller) -> exclusive tile bases in bsum, total (the in-tile scan is redone by
-// the consumer, k_ing_compact)
-static int scan_flags(const uint8_t *flags, int64_t n, int32_t *bsum, int64_t *total, hipStream_t s) {
-  const int nb = (int)(pad_tile(n) / kScanTile);
-  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, s, flags, bsum);
-  hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, bsum, nb, total);
-  return (int)hipGetLastError();
-}
-
 }  // namespace anirec
 
 using namespace anirec;
 
 extern "C" {
 
-// alive | keep (padded byte flags) | bsum | hash table | user counts | anime max | minmax + err
+// keep (byte flags, whole chunks) | list of non-local rows | per-tile counts | hash table of the list | user counts,
+// first row, last row | anime max | minmax, list length.  The list and its table are sized for the worst case
+// (a table in random order: every row non-local); only the part the list needs is ever touched.
+struct IngestWs {
+  uint8_t *keep;
+  int32_t *nl_list, *bsum;
+  unsigned long long *table;
+  int32_t *cnt_u, *ufirst, *ulast, *max_ep;
+  unsigned long long *mm;
+  int32_t *nl_count;
+  size_t bytes;
+};
+static IngestWs carve_ingest(void *workspace, int64_t n, int32_t user_bound, int32_t anime_bound) {
+  const size_t np = pad_tile(n);
+  char *p = (char *)workspace;
+  IngestWs w;
+  w.keep = (uint8_t *)p;
+  p += al256(np);
+  w.nl_list = (int32_t *)p;
+  p += al256((size_t)n * 4);
+  w.bsum = (int32_t *)p;
+  p += al256(np / kScanTile * 4);
+  w.table = (unsigned long long *)p;
+  p += al256((size_t)table_slots(n) * 8);
+  w.cnt_u = (int32_t *)p;
+  p += al256((size_t)user_bound * 4);
+  w.ufirst = (int32_t *)p;
+  p += al256((size_t)user_bound * 4);
+  w.ulast = (int32_t *)p;
+  p += al256((size_t)user_bound * 4);
+  w.max_ep = (int32_t *)p;
+  p += al256((size_t)anime_bound * 4);
+  w.mm = (unsigned long long *)p;
+  w.nl_count = (int32_t *)(p + 16);
+  p += 256;
+  w.bytes = (size_t)(p - (char *)workspace);
+  return w;
+}
+
 size_t anirec_ingest_workspace_bytes(int64_t n, int32_t user_id_bound, int32_t anime_id_bound) {
   if (n < 1 || n >= ((int64_t)1 << 30) || user_id_bound < 1 || anime_id_bound < 1) return 0;
-  const size_t np = pad_tile(n);
-  return 2 * al256(np) + al256(np / kScanTile * 4) + al256((size_t)table_slots(n) * 8) +
-         al256((size_t)user_id_bound * 4) + al256((size_t)anime_id_bound * 4) + 256;
+  return carve_ingest(nullptr, n, user_id_bound, anime_id_bound).bytes;
 }
 
 int anirec_ingest_preprocess(const int32_t *user_id, const int32_t *anime_id, const double *rating,
@@ -458,57 +815,58 @@ int anirec_ingest_preprocess(const int32_t *user_id, const int32_t *anime_id, co
       !out_anime_id || !out_rating || !out_status || !out_episodes || !n_out || !err_flag || !workspace)
     return ANIREC_EINVAL;
   if (n < 1 || n >= ((int64_t)1 << 30) || opts->user_id_bound < 1 || opts->anime_id_bound < 1) return ANIREC_EINVAL;
+  if (!aligned16(user_id) || !aligned16(anime_id) || !aligned16(rating) || !aligned16(watching_status) ||
+      !aligned16(watched_episodes) || !aligned16(workspace))
+    return ANIREC_EINVAL;  // the columns are read 16 bytes at a time
   if (workspace_bytes < anirec_ingest_workspace_bytes(n, opts->user_id_bound, opts->anime_id_bound))
     return ANIREC_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const size_t np = pad_tile(n);
-  const uint32_t slots = table_slots(n);
-  char *p = (char *)workspace;
-  uint8_t *alive = (uint8_t *)p;
-  p += al256(np);
-  uint8_t *keep = (uint8_t *)p;
-  p += al256(np);
-  int32_t *bsum = (int32_t *)p;
-  p += al256(np / kScanTile * 4);
-  unsigned long long *table = (unsigned long long *)p;
-  p += al256((size_t)slots * 8);
-  int32_t *cnt_u = (int32_t *)p;
-  p += al256((size_t)opts->user_id_bound * 4);
-  int32_t *max_ep = (int32_t *)p;
-  p += al256((size_t)opts->anime_id_bound * 4);
-  unsigned long long *mm = (unsigned long long *)p;
+  const IngestWs w = carve_ingest(workspace, n, opts->user_id_bound, opts->anime_id_bound);
+  const int n_tiles = (int)(np / kScanTile);
+  const size_t ub = (size_t)opts->user_id_bound;
 
   const IngestCols c{user_id, anime_id, rating, watching_status, watched_episodes};
   const int g = grid_for(n);
+  const int gl = 4096;  // the list kernels read the list length on the device
   ANIREC_HIP_CHECK(hipMemsetAsync(err_flag, 0, 4, s));
-  ANIREC_HIP_CHECK(hipMemsetAsync(keep + n, 0, np - (size_t)n, s));
-  ANIREC_HIP_CHECK(hipMemsetAsync(alive + n, 0, np - (size_t)n, s));
-  ANIREC_HIP_CHECK(hipMemsetAsync(table, 0xFF, (size_t)slots * 8, s));
-  ANIREC_HIP_CHECK(hipMemsetAsync(cnt_u, 0, (size_t)opts->user_id_bound * 4, s));
-  ANIREC_HIP_CHECK(hipMemsetAsync(mm, 0xFF, 8, s));
-  ANIREC_HIP_CHECK(hipMemsetAsync(mm + 1, 0, 8, s));
-  hipLaunchKernelGGL(k_ing_alive, dim3(g), dim3(256), 0, s, c, n, opts->drop_unwatched, opts->drop_plan,
-                     opts->user_id_bound, opts->anime_id_bound, alive, keep, err_flag);
-  hipLaunchKernelGGL(k_ing_insert, dim3(g), dim3(256), 0, s, c, n, alive, table, slots - 1, keep);
-  hipLaunchKernelGGL(k_ing_count, dim3(g), dim3(256), 0, s, user_id, n, keep, cnt_u);
+  ANIREC_HIP_CHECK(hipMemsetAsync(w.cnt_u, 0, ub * 4, s));
+  ANIREC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)w.ufirst, 0x7FFFFFFF, ub, s));
+  ANIREC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)w.ulast, -1, ub, s));
+  ANIREC_HIP_CHECK(hipMemsetAsync(w.mm, 0xFF, 8, s));
+  ANIREC_HIP_CHECK(hipMemsetAsync(w.mm + 1, 0, 16, s));  // max, list length
+  hipLaunchKernelGGL(k_ing_span, dim3(quad_grid(n, kSpanIters)), dim3(256), 0, s, user_id, n, opts->user_id_bound,
+                     w.ufirst, w.ulast);
+  const FrontArgs fa{c,        n,        opts->drop_unwatched, opts->drop_plan, opts->user_id_bound, opts->anime_id_bound,
+                     opts->num_reviews, n_tiles, w.ufirst, w.ulast, w.keep,
+                     w.bsum,   w.nl_list, w.nl_count, w.mm,   err_flag};
+  const dim3 gf((unsigned)(np / kChunk));
   if (!opts->drop_half_watched) {
-    hipLaunchKernelGGL(k_ing_user_filter<true>, dim3(g > 4096 ? 4096 : g), dim3(256), 0, s, user_id, rating, n, cnt_u,
-                       opts->num_reviews, keep, mm);
+    hipLaunchKernelGGL(k_ing_front<true>, gf, dim3(kFrontThreads), 0, s, fa);
   } else {
-    hipLaunchKernelGGL(k_ing_user_filter<false>, dim3(g), dim3(256), 0, s, user_id, rating, n, cnt_u,
-                       opts->num_reviews, keep, mm);
-    // episodes can be any int32: start the per-anime maxima at INT32_MIN (0x80 bytes give 0x80808080 < 0,
-    // below every non-null value is not guaranteed, so set exactly)
-    ANIREC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)max_ep, (int)0x80000000, (size_t)opts->anime_id_bound, s));
-    hipLaunchKernelGGL(k_ing_anime_max, dim3(g), dim3(256), 0, s, c, n, keep, max_ep);
-    hipLaunchKernelGGL(k_ing_half_filter, dim3(g), dim3(256), 0, s, c, n, max_ep, keep);
-    hipLaunchKernelGGL(k_ing_minmax, dim3(g > 2048 ? 2048 : g), dim3(256), 0, s, rating, n, keep, mm);
+    hipLaunchKernelGGL(k_ing_front<false>, gf, dim3(kFrontThreads), 0, s, fa);
+  }
+  hipLaunchKernelGGL(k_nl_clear, dim3(gl), dim3(256), 0, s, w.table, w.nl_count);
+  hipLaunchKernelGGL(k_nl_insert, dim3(gl), dim3(256), 0, s, c, w.nl_list, w.nl_count, w.table, w.keep, w.bsum);
+  hipLaunchKernelGGL(k_nl_count, dim3(gl), dim3(256), 0, s, user_id, w.nl_list, w.nl_count, w.keep, w.cnt_u);
+  if (!opts->drop_half_watched) {
+    hipLaunchKernelGGL(k_nl_filter<true>, dim3(gl), dim3(256), 0, s, user_id, rating, w.nl_list, w.nl_count, w.cnt_u,
+                       opts->num_reviews, w.keep, w.bsum, w.mm);
+  } else {
+    hipLaunchKernelGGL(k_nl_filter<false>, dim3(gl), dim3(256), 0, s, user_id, rating, w.nl_list, w.nl_count, w.cnt_u,
+                       opts->num_reviews, w.keep, w.bsum, w.mm);
+    // episodes can be any int32: start the per-anime maxima at INT32_MIN
+    ANIREC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)w.max_ep, (int)0x80000000, (size_t)opts->anime_id_bound, s));
+    hipLaunchKernelGGL(k_ing_anime_max, dim3(g), dim3(256), 0, s, c, n, w.keep, w.max_ep);
+    hipLaunchKernelGGL(k_ing_half_filter, dim3(g), dim3(256), 0, s, c, n, w.max_ep, w.keep);
+    hipLaunchKernelGGL(k_ing_minmax, dim3(g > 2048 ? 2048 : g), dim3(256), 0, s, rating, n, w.keep, w.mm);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(n_tiles), dim3(256), 0, s, w.keep, w.bsum);  // the flags changed: recount
   }
   ANIREC_HIP_CHECK(hipGetLastError());
-  int rc = scan_flags(keep, n, bsum, n_out, s);
-  if (rc) return rc;
+  // per-tile counts -> exclusive tile bases + total; the in-tile scan is k_ing_compact's
+  hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, w.bsum, n_tiles, n_out);
   const IngestOut o{out_user_id, out_anime_id, out_rating, out_status, out_episodes};
-  hipLaunchKernelGGL(k_ing_compact, dim3((unsigned)(np / kScanTile)), dim3(256), 0, s, c, n, keep, bsum, mm, o);
+  hipLaunchKernelGGL(k_ing_compact, dim3((unsigned)n_tiles), dim3(256), 0, s, c, n, w.keep, w.bsum, w.mm, o);
   return (int)hipGetLastError();
 }
 
@@ -520,13 +878,9 @@ int anirec_ingest_half_columns(const int32_t *out_anime_id, const int64_t *n_out
   if (!opts->drop_half_watched) return ANIREC_EINVAL;  // the per-anime maxima only exist after that pass
   if (workspace_bytes < anirec_ingest_workspace_bytes(n, opts->user_id_bound, opts->anime_id_bound))
     return ANIREC_EWORKSPACE;
-  // same carve as anirec_ingest_preprocess: the per-anime maxima sit behind the user counts
-  const size_t np = pad_tile(n);
-  const char *p = (const char *)workspace;
-  p += 2 * al256(np) + al256(np / kScanTile * 4) + al256((size_t)table_slots(n) * 8) +
-       al256((size_t)opts->user_id_bound * 4);
+  const IngestWs w = carve_ingest(const_cast<void *>(workspace), n, opts->user_id_bound, opts->anime_id_bound);
   hipLaunchKernelGGL(k_ing_half_columns, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out_anime_id, n_out,
-                     (const int32_t *)p, out_max_eps, out_half_eps);
+                     (const int32_t *)w.max_ep, out_max_eps, out_half_eps);
   return (int)hipGetLastError();
 }
 
@@ -544,6 +898,7 @@ int anirec_ingest_encode(const int32_t *id, int64_t n, int32_t id_bound, int32_t
                          void *stream) {
   if (!id || !out_index || !out_uniques || !n_unique || !err_flag || !workspace) return ANIREC_EINVAL;
   if (n < 1 || n >= ((int64_t)1 << 30) || id_bound < 1) return ANIREC_EINVAL;
+  if (!aligned16(id) || !aligned16(out_index) || !aligned16(workspace)) return ANIREC_EINVAL;  // 16-byte accesses
   if (workspace_bytes < anirec_ingest_encode_workspace_bytes(n, id_bound)) return ANIREC_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const size_t nw = bit_words(n);
@@ -555,19 +910,18 @@ int anirec_ingest_encode(const int32_t *id, int64_t n, int32_t id_bound, int32_t
   int32_t *wpre = (int32_t *)p;
   p += al256(nw * 4);
   int32_t *bsum = (int32_t *)p;
-  const int g = grid_for(n);
   const int gb = (id_bound + 255) / 256;
   const int nb = (int)(nw / kBitTile);
   ANIREC_HIP_CHECK(hipMemsetAsync(err_flag, 0, 4, s));
   ANIREC_HIP_CHECK(hipMemsetAsync(bits, 0, nw * 4, s));
   ANIREC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)first, 0x7FFFFFFF, (size_t)id_bound, s));
-  hipLaunchKernelGGL(k_enc_first, dim3(g), dim3(256), 0, s, id, n, id_bound, first, err_flag);
+  hipLaunchKernelGGL(k_enc_first, dim3(quad_grid(n, kEncIters)), dim3(256), 0, s, id, n, id_bound, first, err_flag);
   hipLaunchKernelGGL(k_enc_bits, dim3(gb), dim3(256), 0, s, first, id_bound, bits);
   hipLaunchKernelGGL(k_bits_reduce, dim3(nb), dim3(256), 0, s, bits, bsum);
   hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, bsum, nb, n_unique);
   hipLaunchKernelGGL(k_bits_apply, dim3(nb), dim3(256), 0, s, bits, bsum, wpre);
   hipLaunchKernelGGL(k_enc_rank, dim3(gb), dim3(256), 0, s, first, id_bound, bits, wpre, out_uniques);
-  hipLaunchKernelGGL(k_enc_emit, dim3(g), dim3(256), 0, s, id, n, id_bound, first, out_index);
+  hipLaunchKernelGGL(k_enc_emit, dim3(quad_grid(n, kEncIters)), dim3(256), 0, s, id, n, id_bound, first, out_index);
   return (int)hipGetLastError();
 }
 

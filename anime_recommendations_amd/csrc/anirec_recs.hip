@@ -235,62 +235,113 @@ struct RecsArgs {
 constexpr int kRecsMaxSim = 64;
 constexpr int kRecsMaxOut = 256;
 
+// Everything stays BIT-SLICED in registers: a lane owns kR words of 32 anime; plane p of `cp` holds bit p of the
+// count of each of a word's 32 anime, so one similar user's 32 favourite bits are added to all 32 counts with a
+// 6-step carry chain, and `bp` holds, the same way, the rank of the FIRST similar user holding the anime (they come
+// best first).  The selection never unpacks them: "count == c", "count > cut", "best < cut_b" are bitwise
+// comparators over the planes, histograms are popcounts of those masks, and only the <= n_recs winners are
+// turned into (count, best, anime) entries.  (The first version wrote a 2-byte key per anime to LDS and walked
+// the 18 k of them four times: 69 us per query, 0.046 of the HBM rate of the 11 bit rows it reads.)
+//
+// gt / eq masks of the 6-plane numbers of a word against the scalar v
+__device__ __forceinline__ void cmp_planes(const uint32_t (&pl)[6], uint32_t v, uint32_t &gt, uint32_t &eq) {
+  gt = 0u;
+  eq = ~0u;
+#pragma unroll
+  for (int p = 5; p >= 0; --p) {
+    const uint32_t vb = ((v >> p) & 1u) ? ~0u : 0u;
+    gt |= eq & pl[p] & ~vb;
+    eq &= ~(pl[p] ^ vb);
+  }
+}
+__device__ __forceinline__ uint32_t plane_value(const uint32_t (&pl)[6], int b) {
+  uint32_t v = 0;
+#pragma unroll
+  for (int p = 0; p < 6; ++p) v |= ((pl[p] >> b) & 1u) << p;
+  return v;
+}
+
+template <int kR>
 __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
-  // key[anime] = (count << 6) | (63 - best_rank), 0 = not recommended: 2 B per anime (36 KB at 18 k anime,
-  // four workgroups per CU)
-  extern __shared__ uint16_t sm[];
   __shared__ uint32_t win[kRecsMaxOut];  // winners: count (7 bits) | 63 - best (8 bits) | anime (17 bits)
   __shared__ int hist[kRecsMaxSim + 1], hist2[kRecsMaxSim + 1];
-  __shared__ int sh_cut, sh_room, sh_cut_b, sh_room2;
+  __shared__ int sims[kRecsMaxSim];
+  __shared__ int sh_cut, sh_room, sh_cut_b, sh_room2, sh_scan, n_win;
   __shared__ int wsum[4];
-  const int q = blockIdx.x, tid = threadIdx.x;
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int qu = a.query[q];
-  const int n_pad = a.wwords * 32;
-  for (int w = tid; w < a.wwords; w += 256) {
-    // Bit-sliced (vertical) counters: plane p of `cp` holds bit p of the count of each of the word's 32
-    // anime, so one similar user's 32 favourite bits are added to all 32 counts with a 6-step carry chain;
-    // `bp` holds, the same way, the rank of the FIRST similar user holding the anime (they come best first).
-    uint32_t cp[6] = {0u, 0u, 0u, 0u, 0u, 0u}, bp[6] = {0u, 0u, 0u, 0u, 0u, 0u}, seen = 0u;
-    for (int j = 0; j < a.k_sim; ++j) {
-      const int su = a.sim[(size_t)q * a.k_sim + j];
-      if (su < 0 || su >= a.n_users) continue;
-      const uint32_t bits = a.fav[(size_t)su * a.wwords + w];
-      uint32_t carry = bits;
-#pragma unroll
-      for (int p = 0; p < 6; ++p) {
-        const uint32_t t = cp[p] & carry;
-        cp[p] ^= carry;
-        carry = t;
-      }
-      const uint32_t fresh = bits & ~seen;
-      seen |= bits;
-#pragma unroll
-      for (int p = 0; p < 6; ++p)
-        if ((j >> p) & 1) bp[p] |= fresh;
-    }
-    const uint32_t own = (qu >= 0 && qu < a.n_users) ? a.fav[(size_t)qu * a.wwords + w] : 0u;
-    const uint32_t ok = seen & ~own;
-#pragma unroll
-    for (int b = 0; b < 32; ++b) {
-      const int an = w * 32 + b;
-      uint32_t cnt = 0, best = 0;
-#pragma unroll
-      for (int p = 0; p < 6; ++p) {
-        cnt |= ((cp[p] >> b) & 1u) << p;
-        best |= ((bp[p] >> b) & 1u) << p;
-      }
-      sm[an] = (((ok >> b) & 1u) && an < a.n_anime) ? (uint16_t)((cnt << 6) | (63u - best)) : (uint16_t)0;
-    }
+  if (tid < a.k_sim) {
+    const int su = a.sim[(size_t)q * a.k_sim + tid];
+    sims[tid] = (su < 0 || su >= a.n_users) ? -1 : su;
   }
   for (int c = tid; c <= kRecsMaxSim; c += 256) {
     hist[c] = 0;
     hist2[c] = 0;
   }
+  if (tid == 0) n_win = 0;
   __syncthreads();
+
+  uint32_t cp[kR][6], bp[kR][6], ok[kR];
+  {
+    uint32_t seen[kR];
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+      seen[r] = 0u;
+#pragma unroll
+      for (int p = 0; p < 6; ++p) cp[r][p] = 0u, bp[r][p] = 0u;
+    }
+    // the next similar user's words are in flight while this one's are added (an empty slot adds zeros)
+    auto load_row = [&](int j, uint32_t (&dst)[kR]) {
+      const int su = sims[j];
+      const uint32_t *row = a.fav + (size_t)(su < 0 ? 0 : su) * a.wwords;
+#pragma unroll
+      for (int r = 0; r < kR; ++r) {
+        const int w = r * 256 + tid;
+        dst[r] = (su >= 0 && w < a.wwords) ? row[w] : 0u;
+      }
+    };
+    uint32_t nxt[kR];
+    load_row(0, nxt);
+    for (int j = 0; j < a.k_sim; ++j) {
+      uint32_t bits[kR];
+#pragma unroll
+      for (int r = 0; r < kR; ++r) bits[r] = nxt[r];
+      if (j + 1 < a.k_sim) load_row(j + 1, nxt);
+#pragma unroll
+      for (int r = 0; r < kR; ++r) {
+        uint32_t carry = bits[r];
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+          const uint32_t t = cp[r][p] & carry;
+          cp[r][p] ^= carry;
+          carry = t;
+        }
+        const uint32_t fresh = bits[r] & ~seen[r];
+        seen[r] |= bits[r];
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+          if ((j >> p) & 1) bp[r][p] |= fresh;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+      const int w = r * 256 + tid;
+      const uint32_t own = (qu >= 0 && qu < a.n_users && w < a.wwords) ? a.fav[(size_t)qu * a.wwords + w] : 0u;
+      const int left = a.n_anime - w * 32;  // bits of the last word past n_anime are not anime
+      const uint32_t valid = left >= 32 ? ~0u : (left > 0 ? (1u << left) - 1u : 0u);
+      ok[r] = seen[r] & ~own & valid;
+    }
+  }
   // level 1: histogram of counts -> the count value `cut` at which the top n_recs end
-  for (int an = tid; an < n_pad; an += 256) {
-    const uint32_t k = sm[an];
-    if (k) atomicAdd(&hist[k >> 6], 1);
+#pragma unroll
+  for (int r = 0; r < kR; ++r) {
+    if (!ok[r]) continue;
+    for (int c = 1; c <= a.k_sim; ++c) {
+      uint32_t gt, eq;
+      cmp_planes(cp[r], (uint32_t)c, gt, eq);
+      const int n = __popc(eq & ok[r]);
+      if (n) atomicAdd(&hist[c], n);
+    }
   }
   __syncthreads();
   if (tid == 0) {
@@ -305,10 +356,19 @@ __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
   __syncthreads();
   const int cut = sh_cut;
   // level 2: among count == cut, histogram of the best similar-user rank -> rank `cut_b`
-  if (cut > 0) {
-    for (int an = tid; an < n_pad; an += 256) {
-      const uint32_t k = sm[an];
-      if (k && (int)(k >> 6) == cut) atomicAdd(&hist2[63 - (int)(k & 63u)], 1);
+  uint32_t sure[kR], atcut[kR];
+#pragma unroll
+  for (int r = 0; r < kR; ++r) {
+    uint32_t gt, eq;
+    cmp_planes(cp[r], (uint32_t)cut, gt, eq);
+    sure[r] = cut == 0 ? ok[r] : (gt & ok[r]);
+    atcut[r] = cut == 0 ? 0u : (eq & ok[r]);
+    if (!atcut[r]) continue;
+    for (int b = 0; b < a.k_sim; ++b) {
+      uint32_t g2, e2;
+      cmp_planes(bp[r], (uint32_t)b, g2, e2);
+      const int n = __popc(e2 & atcut[r]);
+      if (n) atomicAdd(&hist2[b], n);
     }
   }
   __syncthreads();
@@ -322,55 +382,73 @@ __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
     }
     sh_cut_b = r;               // best rank < cut_b: taken; == cut_b: the first `room2` in anime-index order
     sh_room2 = sh_room - cum;
+    sh_scan = (cut > 0 && r < a.k_sim && hist2[r] > sh_room - cum) ? 1 : 0;  // more ties than room: order matters
   }
   __syncthreads();
   const int cut_b = sh_cut_b, room2 = sh_room2;
-  // level 3 + gather (anime index ascending): exactly min(n_recs, #candidates) winners
-  int n_out = 0, tie_seen = 0;
-  for (int base = 0; base < n_pad; base += 256) {
-    const int an = base + tid;
-    const uint32_t k = an < n_pad ? sm[an] : 0u;
-    const int cnt = (int)(k >> 6), best = 63 - (int)(k & 63u);
-    const bool sure = k != 0u && (cut == 0 || cnt > cut || (cnt == cut && best < cut_b));
-    const bool tie = k != 0u && cut > 0 && cnt == cut && best == cut_b;
-    if (!__syncthreads_or(sure || tie)) continue;  // most 256-anime chunks hold no winner: one barrier, not four
-    const int lane = tid & 63, w = tid >> 6;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const unsigned long long mt = __ballot(tie);
-    if (lane == 0) wsum[w] = __popcll(mt);
-    __syncthreads();
-    int tie_off = tie_seen;
-    for (int x = 0; x < w; ++x) tie_off += wsum[x];
-    const int tie_tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    const bool take = sure || (tie && tie_off + __popcll(mt & below) < room2);
-    __syncthreads();
-    const unsigned long long m = __ballot(take);
-    if (lane == 0) wsum[w] = __popcll(m);
-    __syncthreads();
-    int off = n_out;
-    for (int x = 0; x < w; ++x) off += wsum[x];
-    const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    const int pos = off + __popcll(m & below);
-    if (take && pos < kRecsMaxOut) win[pos] = ((uint32_t)cnt << 25) | ((k & 63u) << 17) | (uint32_t)an;
-    n_out += tot;
-    tie_seen += tie_tot;
-    __syncthreads();
+  // level 3: exactly min(n_recs, #candidates) winners
+  uint32_t tie[kR];
+#pragma unroll
+  for (int r = 0; r < kR; ++r) {
+    uint32_t g2, e2;
+    cmp_planes(bp[r], (uint32_t)cut_b, g2, e2);
+    sure[r] |= atcut[r] & ~g2 & ~e2;  // count == cut and best < cut_b
+    tie[r] = atcut[r] & e2;
   }
-  if (n_out > kRecsMaxOut) n_out = kRecsMaxOut;
-  // exact order of the n_out (<= n_recs) winners: (count, 63 - best) descending, anime index ascending
+  if (sh_scan) {  // the first room2 ties in anime-index order: words ascend with r, then with the lane
+    int seen_ties = 0;
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+      const int mine = __popc(tie[r]);
+      int incl = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += y;
+      }
+      if (lane == 63) wsum[tid >> 6] = incl;
+      __syncthreads();
+      int before = seen_ties + incl - mine;
+      for (int x = 0; x < (tid >> 6); ++x) before += wsum[x];
+      seen_ties += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+      __syncthreads();
+      int room = room2 - before;  // ties of this word still to take, lowest bits first
+      uint32_t t = tie[r], takem = 0u;
+      while (t && room > 0) {
+        const uint32_t low = t & (0u - t);
+        takem |= low;
+        t ^= low;
+        --room;
+      }
+      tie[r] = takem;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kR; ++r) {
+    uint32_t take = sure[r] | tie[r];
+    while (take) {
+      const int b = __ffs(take) - 1;
+      take &= take - 1u;
+      const int pos = atomicAdd(&n_win, 1);
+      if (pos < kRecsMaxOut)
+        win[pos] = (plane_value(cp[r], b) << 25) | ((63u - plane_value(bp[r], b)) << 17) | (uint32_t)((r * 256 + tid) * 32 + b);
+    }
+  }
   for (int i = tid; i < a.n_recs; i += 256) {
     a.out_anime[(size_t)q * a.n_recs + i] = -1;
     a.out_count[(size_t)q * a.n_recs + i] = 0;
   }
   __syncthreads();
+  const int n_out = n_win > kRecsMaxOut ? kRecsMaxOut : n_win;
+  // exact order of the n_out (<= n_recs) winners: (count, 63 - best) descending, anime index ascending
   for (int i = tid; i < n_out; i += 256) {
     const uint32_t me = win[i];
     const uint32_t mk = me >> 17, ma = me & 0x1FFFFu;
     int rank = 0;
     for (int j = 0; j < n_out; ++j) {
       const uint32_t o = win[j];
-      const uint32_t ok = o >> 17, oa = o & 0x1FFFFu;
-      rank += (ok > mk || (ok == mk && oa < ma)) ? 1 : 0;
+      const uint32_t okk = o >> 17, oa = o & 0x1FFFFu;
+      rank += (okk > mk || (okk == mk && oa < ma)) ? 1 : 0;
     }
     if (rank < a.n_recs) {
       a.out_anime[(size_t)q * a.n_recs + rank] = (int32_t)ma;
@@ -453,14 +531,20 @@ int anirec_user_recs(const uint32_t *fav_bits, int32_t n_users, int32_t n_anime,
   a.n_recs = n_recs;
   a.out_anime = out_anime;
   a.out_count = out_count;
-  const size_t shm = (size_t)wwords * 32 * 2;  // 2 B per anime: 36 KB at 18 k anime
-  if (shm > 150 * 1024) return ANIREC_EINVAL;
-  static bool attr_set = false;
-  if (!attr_set) {
-    ANIREC_HIP_CHECK(hipFuncSetAttribute((const void *)k_user_recs, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr_set = true;
+  // a lane holds kR words of 32 anime in registers
+  if (wwords <= 256) {
+    hipLaunchKernelGGL(k_user_recs<1>, dim3(nq), dim3(256), 0, (hipStream_t)stream, a);
+  } else if (wwords <= 2 * 256) {
+    hipLaunchKernelGGL(k_user_recs<2>, dim3(nq), dim3(256), 0, (hipStream_t)stream, a);
+  } else if (wwords <= 3 * 256) {
+    hipLaunchKernelGGL(k_user_recs<3>, dim3(nq), dim3(256), 0, (hipStream_t)stream, a);  // 17 560 anime: 549 words
+  } else if (wwords <= 4 * 256) {
+    hipLaunchKernelGGL(k_user_recs<4>, dim3(nq), dim3(256), 0, (hipStream_t)stream, a);
+  } else if (wwords <= 8 * 256) {
+    hipLaunchKernelGGL(k_user_recs<8>, dim3(nq), dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL(k_user_recs<16>, dim3(nq), dim3(256), 0, (hipStream_t)stream, a);  // n_anime < 2^17
   }
-  hipLaunchKernelGGL(k_user_recs, dim3(nq), dim3(256), shm, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

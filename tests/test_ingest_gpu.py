@@ -11,7 +11,7 @@ from oracle import ingest_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def _raw_frame(n, n_users, n_anime, seed, nulls=True, dups=True):
+def _raw_frame(n, n_users, n_anime, seed, nulls=True, dups=True, grouped=False):
     rng = np.random.default_rng(seed)
     users = np.sort(rng.choice(np.arange(1, 5 * n_users), n_users, replace=False))
     animes = rng.choice(np.arange(1, 3 * n_anime), n_anime, replace=False)
@@ -33,6 +33,8 @@ def _raw_frame(n, n_users, n_anime, seed, nulls=True, dups=True):
                         "watching_status": "float64", "watched_episodes": "float64"})
         for col in df.columns:
             df.loc[rng.integers(0, n, max(1, n // 500)), col] = np.nan
+    if grouped:  # the raw animelist: one block of rows per user (duplicates stay inside their user's block)
+        df = df.sort_values("user_id", kind="stable").reset_index(drop=True)
     return df
 
 
@@ -62,6 +64,28 @@ def test_preprocess_matches_pandas(flags):
     df = _raw_frame(200_000, 900, 700, seed=3)
     want = _check(df, 150, **flags)
     assert 0 < len(want) < len(df)
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(drop_plan=True), dict(drop_unwatched=True, drop_half_watched=True)])
+@pytest.mark.parametrize("shape", [(200_000, 900), (200_000, 7), (70_000, 1), (16_384 * 3, 48), (16_385, 300)])
+def test_preprocess_grouped_by_user(flags, shape):
+    """The layout of the raw animelist: users in blocks.  Blocks inside one 16 384-row chunk take the LDS path
+    of k_ing_front, blocks that straddle a chunk boundary (or are longer than a chunk: 7 users, 1 user) the
+    list path; both must give pandas' answer, including duplicates whose first occurrence sits in another chunk."""
+    n, n_users = shape
+    df = _raw_frame(n, n_users, 700, seed=21 + n_users, grouped=True)
+    want = _check(df, max(2, n // n_users // 2), **flags)
+    assert len(want) > 0
+    # and with a threshold no straddling user passes
+    _check(df, n // n_users * 2, **flags) if n_users > 1 else None
+
+
+def test_preprocess_grouped_many_duplicates():
+    """Every row appears 3 times inside its user's block (first occurrence wins, order kept)."""
+    df = _raw_frame(40_000, 150, 90, seed=33, nulls=False, dups=False, grouped=True)
+    df = pd.concat([df, df, df], ignore_index=True).sort_values("user_id", kind="stable").reset_index(drop=True)
+    want = _check(df, 50)
+    assert len(want) <= 40_000
 
 
 def test_preprocess_no_nulls_integer_columns():
@@ -114,15 +138,18 @@ def test_preprocess_then_encode_feeds_training_layout():
     np.testing.assert_array_equal(enc.anime_ids.cpu().numpy(), ref.anime_ids)
 
 
-def test_fullsize_properties_109m_rows():
+@pytest.mark.parametrize("grouped", [True, False])
+def test_fullsize_properties_109m_rows(grouped):
     """BASELINE size (109 M rows): no oracle run, size-independent properties instead —
-    idempotence, order preservation, per-user counts >= num_reviews, no duplicate rows."""
+    idempotence, order preservation, per-user counts >= num_reviews, no duplicate rows.  Grouped by user (the raw
+    animelist: the LDS path) and in random order (every row through the list and the global table)."""
     from anime_recommendations_amd import ingest
     n, n_users, n_anime = 109_000_000, 350_000, 18_000
     g = torch.Generator(device="cuda")
     g.manual_seed(17)
+    users = torch.randint(0, n_users, (n,), generator=g, device="cuda", dtype=torch.int32)
     cols = {
-        "user_id": torch.randint(0, n_users, (n,), generator=g, device="cuda", dtype=torch.int32),
+        "user_id": torch.sort(users)[0] if grouped else users,
         "anime_id": torch.randint(0, n_anime, (n,), generator=g, device="cuda", dtype=torch.int32),
         "rating": torch.randint(0, 11, (n,), generator=g, device="cuda", dtype=torch.int32).double(),
         "watching_status": torch.randint(1, 7, (n,), generator=g, device="cuda", dtype=torch.int32),

@@ -93,3 +93,31 @@ def test_many_ties_at_the_cut_and_large_k():
     want_a, want_c = orc.user_recs(fav_o, 69, sims[0].tolist(), 20)
     assert out_a.cpu().numpy()[0].tolist() == want_a and out_c.cpu().numpy()[0].tolist() == want_c
     assert want_c == [63] * 20
+
+
+@pytest.mark.parametrize("n_anime", [31, 8_192, 17_560, 40_000, 100_000, 131_071])
+def test_user_recs_wide_tables(n_anime):
+    """The kernel keeps 1, 2, 3, 4, 8 or 16 bit words per lane depending on the number of anime: every width, with
+    favourites concentrated so that many anime tie at the cut across several words."""
+    from anime_recommendations_amd import recs
+    rng = np.random.default_rng(n_anime)
+    n_users, k_sim, n_recs = 120, 9, 25
+    per = 300
+    u = np.repeat(np.arange(n_users), per).astype(np.int32)
+    # half of each user's ratings from a pool shared by all (ties at high counts), half anywhere in the table
+    pool = rng.choice(n_anime, min(n_anime, 200), replace=False)
+    a = np.where(rng.random(len(u)) < .5, pool[rng.integers(0, len(pool), len(u))],
+                 rng.integers(0, n_anime, len(u))).astype(np.int32)
+    r = rng.integers(1, 11, len(u)).astype(np.float64)
+    _, fav_o = orc.favourites(u, a, r, n_users)
+    fav, _ = recs.user_favourites(torch.as_tensor(u).cuda(), torch.as_tensor(a).cuda(), torch.as_tensor(r).cuda(),
+                                  n_users, n_anime)
+    queries = rng.integers(0, n_users, 24).astype(np.int32)
+    sims = np.stack([rng.choice(n_users, k_sim, replace=False) for _ in queries]).astype(np.int32)
+    out_a, out_c = recs.user_recs(fav, n_anime, queries, sims, n_recs)
+    out_a, out_c = out_a.cpu().numpy(), out_c.cpu().numpy()
+    for j, q in enumerate(queries):
+        want_a, want_c = orc.user_recs(fav_o, int(q), sims[j].tolist(), n_recs)
+        m = len(want_a)
+        assert out_a[j, :m].tolist() == want_a and out_c[j, :m].tolist() == want_c, j
+        assert (out_a[j, m:] == -1).all() and (out_c[j, m:] == 0).all()
