@@ -290,23 +290,27 @@ __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
 #pragma unroll
       for (int p = 0; p < 6; ++p) cp[r][p] = 0u, bp[r][p] = 0u;
     }
-    // the next similar user's words are in flight while this one's are added (an empty slot adds zeros)
-    auto load_row = [&](int j, uint32_t (&dst)[kR]) {
-      const int su = sims[j];
-      const uint32_t *row = a.fav + (size_t)(su < 0 ? 0 : su) * a.wwords;
+    // the words of kB similar users are requested together (an empty slot adds zeros): a workgroup's 11 rows are
+    // scattered over the 350 k-user bit matrix, so the loop is bound by how many row reads are in flight
+    constexpr int kB = kR <= 3 ? 10 : (kR == 4 ? 8 : (kR == 8 ? 4 : 2));
+    for (int j0 = 0; j0 < a.k_sim; j0 += kB) {
+      uint32_t batch[kB][kR];
 #pragma unroll
-      for (int r = 0; r < kR; ++r) {
-        const int w = r * 256 + tid;
-        dst[r] = (su >= 0 && w < a.wwords) ? row[w] : 0u;
+      for (int jj = 0; jj < kB; ++jj) {
+        const int su = j0 + jj < a.k_sim ? sims[j0 + jj] : -1;
+        const uint32_t *row = a.fav + (size_t)(su < 0 ? 0 : su) * a.wwords;
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+          const int w = r * 256 + tid;
+          batch[jj][r] = (su >= 0 && w < a.wwords) ? row[w] : 0u;
+        }
       }
-    };
-    uint32_t nxt[kR];
-    load_row(0, nxt);
-    for (int j = 0; j < a.k_sim; ++j) {
-      uint32_t bits[kR];
 #pragma unroll
-      for (int r = 0; r < kR; ++r) bits[r] = nxt[r];
-      if (j + 1 < a.k_sim) load_row(j + 1, nxt);
+      for (int jj = 0; jj < kB; ++jj) {
+        const int j = j0 + jj;
+        uint32_t bits[kR];
+#pragma unroll
+        for (int r = 0; r < kR; ++r) bits[r] = batch[jj][r];
 #pragma unroll
       for (int r = 0; r < kR; ++r) {
         uint32_t carry = bits[r];
@@ -322,6 +326,7 @@ __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
         for (int p = 0; p < 6; ++p)
           if ((j >> p) & 1) bp[r][p] |= fresh;
       }
+      }
     }
 #pragma unroll
     for (int r = 0; r < kR; ++r) {
@@ -332,16 +337,19 @@ __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
       ok[r] = seen[r] & ~own & valid;
     }
   }
-  // level 1: histogram of counts -> the count value `cut` at which the top n_recs end
+  // level 1: histogram of counts -> the count value `cut` at which the top n_recs end.  Summed over the wave
+  // before it goes to LDS: most candidates have count 1, and 256 lanes adding to one LDS word serialise.
+  for (int c = 1; c <= a.k_sim; ++c) {
+    int n = 0;
 #pragma unroll
-  for (int r = 0; r < kR; ++r) {
-    if (!ok[r]) continue;
-    for (int c = 1; c <= a.k_sim; ++c) {
+    for (int r = 0; r < kR; ++r) {
       uint32_t gt, eq;
       cmp_planes(cp[r], (uint32_t)c, gt, eq);
-      const int n = __popc(eq & ok[r]);
-      if (n) atomicAdd(&hist[c], n);
+      n += __popc(eq & ok[r]);
     }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o, 64);
+    if (lane == 0 && n) atomicAdd(&hist[c], n);
   }
   __syncthreads();
   if (tid == 0) {
@@ -356,19 +364,27 @@ __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
   __syncthreads();
   const int cut = sh_cut;
   // level 2: among count == cut, histogram of the best similar-user rank -> rank `cut_b`
-  uint32_t sure[kR], atcut[kR];
+  uint32_t sure[kR], atcut[kR], any_cut = 0u;
 #pragma unroll
   for (int r = 0; r < kR; ++r) {
     uint32_t gt, eq;
     cmp_planes(cp[r], (uint32_t)cut, gt, eq);
     sure[r] = cut == 0 ? ok[r] : (gt & ok[r]);
     atcut[r] = cut == 0 ? 0u : (eq & ok[r]);
-    if (!atcut[r]) continue;
+    any_cut |= atcut[r];
+  }
+  if (__ballot(any_cut != 0u)) {
     for (int b = 0; b < a.k_sim; ++b) {
-      uint32_t g2, e2;
-      cmp_planes(bp[r], (uint32_t)b, g2, e2);
-      const int n = __popc(e2 & atcut[r]);
-      if (n) atomicAdd(&hist2[b], n);
+      int n = 0;
+#pragma unroll
+      for (int r = 0; r < kR; ++r) {
+        uint32_t g2, e2;
+        cmp_planes(bp[r], (uint32_t)b, g2, e2);
+        n += __popc(e2 & atcut[r]);
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o, 64);
+      if (lane == 0 && n) atomicAdd(&hist2[b], n);
     }
   }
   __syncthreads();

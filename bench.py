@@ -383,10 +383,10 @@ def run_ingest(cpu_baseline=True):
         "watching_status": torch.randint(1, 7, (n,), generator=g, device="cuda", dtype=torch.int32),
         "watched_episodes": torch.randint(0, 26, (n,), generator=g, device="cuda", dtype=torch.int32),
     }
-    dup_dst = torch.randint(0, n, (n // 200,), generator=g, device="cuda")
-    dup_src = torch.clamp(dup_dst - torch.randint(1, 50, (n // 200,), generator=g, device="cuda"), min=0)
+    dup_dst = torch.unique(torch.randint(0, n, (n // 200,), generator=g, device="cuda"))
+    dup_src = torch.clamp(dup_dst - torch.randint(1, 50, (dup_dst.numel(),), generator=g, device="cuda"), min=0)
     for k in cols:                                       # duplicate rows near their originals (same user)
-        cols[k][dup_dst] = cols[k][dup_src]
+        cols[k][dup_dst] = cols[k].clone()[dup_src]      # (unique targets, untouched sources: reproducible)
 
     def once():
         out = ingest.preprocess_columns(cols, num_reviews=250, drop_plan=True)
@@ -406,14 +406,15 @@ def run_ingest(cpu_baseline=True):
     gbs = alg_bytes / dt / 1e9
     rec = {"value": n / dt, "unit": "rows/s", "ms": dt * 1e3, "rows_in": n, "rows_out": m,
            "n_users": int(enc_u[1].numel()), "n_anime": int(enc_a[1].numel()),
-           "roofline": {"kernel": "ingest pipeline (13 launches; k_ing_insert, the duplicate-row hash table, is "
-                                  "55 % of it: one random 8-B CAS per row in a 2 GB table)",
+           "roofline": {"kernel": "ingest pipeline (22 launches; k_ing_front — row filters, LDS dedupe and per-user "
+                                  "counts of an 8 192-row chunk — and k_ing_compact are 2/3 of it)",
                         "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes,
-                        "traffic": pmc_traffic("ingest", {"k_ing_alive": 1, "k_ing_insert": 1, "k_ing_count": 1,
-                                                          "k_ing_user_filter<true>": 1, "k_ing_compact": 1,
-                                                          "k_scan_reduce": 3, "k_scan_spine": 3, "k_scan_apply": 3,
-                                                          "k_enc_first": 2, "k_enc_flag": 2, "k_enc_emit": 2},
+                        "traffic": pmc_traffic("ingest", {"k_ing_span": 1, "k_ing_front<true>": 1, "k_nl_clear": 1,
+                                                          "k_nl_insert": 1, "k_nl_count": 1, "k_nl_filter<true>": 1,
+                                                          "k_scan_spine": 3, "k_ing_compact": 1,
+                                                          "k_enc_first": 2, "k_enc_bits": 2, "k_bits_reduce": 2,
+                                                          "k_bits_apply": 2, "k_enc_rank": 2, "k_enc_emit": 2},
                                              source="anirec_ingest.hip")}}
     if cpu_baseline:
         import pandas as pd
@@ -529,9 +530,9 @@ def run_user_recs(cpu_baseline=True):
                           "roofline": {"kernel": "k_rec_count/scatter/percentile/favbits (5 launches)", "bound": "hbm",
                                        "achieved": fav_bytes / dt_f / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": fav_bytes / dt_f / 1e9 / HBM_PEAK_GBS, "traffic": None}},
-           "roofline": {"kernel": "k_user_recs (one workgroup per query: 11 bit rows of 2.25 KB -> LDS counts -> top-10)",
+           "roofline": {"kernel": "k_user_recs<3> (one workgroup per query: 11 bit rows of 2.25 KB -> bit-sliced counts in registers -> top-10)",
                         "bound": "hbm", "achieved": rec_bytes / dt_r / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": rec_bytes / dt_r / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("recs", "k_user_recs", source="anirec_recs.hip")}}
+                        "frac": rec_bytes / dt_r / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("recs", "k_user_recs<3>", source="anirec_recs.hip")}}
     if cpu_baseline:
         from oracle import recs_oracle
         nu_s = 2_000                                       # users 0..1999 of the same table

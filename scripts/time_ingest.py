@@ -17,10 +17,10 @@ cols = {
     "watched_episodes": torch.randint(0, 26, (n,), generator=g, device="cuda", dtype=torch.int32),
 }
 if "nodups" not in sys.argv:   # as bench.py run_ingest: ~0.5 % duplicate rows near their originals (same user)
-    dup_dst = torch.randint(0, n, (n // 200,), generator=g, device="cuda")
-    dup_src = torch.clamp(dup_dst - torch.randint(1, 50, (n // 200,), generator=g, device="cuda"), min=0)
+    dup_dst = torch.unique(torch.randint(0, n, (n // 200,), generator=g, device="cuda"))
+    dup_src = torch.clamp(dup_dst - torch.randint(1, 50, (dup_dst.numel(),), generator=g, device="cuda"), min=0)
     for k in cols:
-        cols[k][dup_dst] = cols[k][dup_src]
+        cols[k][dup_dst] = cols[k].clone()[dup_src]
 for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     out = ingest.preprocess_columns(cols, num_reviews=250, drop_plan=True)
