@@ -265,11 +265,14 @@ def _cosine_leg(W, nq, k, cpu_baseline, reps=3, slice_note=None, traffic_name=No
         cand_ms += ms
         cand_launches += nl
     tfk = flops / (cand_ms * 1e-3) / 1e12
-    # HBM bytes of all k_cand launches of ONE call on the profiled 65 536-query slice (scripts/time_topk.py makes 2
-    # calls), scaled to this leg's query count
-    traffic = pmc_traffic(traffic_name, ["k_cand<0, 8, false>"], source="anirec_topk_mfma.hip", calls=2) if traffic_name else None
+    # HBM bytes of all k_cand launches of ONE call of the profiled run (scripts/time_topk.py makes 3 calls; the
+    # 350 k-key profiles are a 65 536-query slice), scaled to this leg's query count
+    traffic = None
+    if traffic_name:
+        for kern in ("k_cand<0, 8, false>", "k_cand<0, 4, false>"):   # 256- or 128-row workgroups (chosen by nq)
+            traffic = traffic or pmc_traffic(traffic_name[0], [kern], source="anirec_topk_mfma.hip", calls=3)
     if traffic is not None:
-        traffic *= nq / 65536.0
+        traffic *= nq / float(traffic_name[1])
     rec = {"value": nq / dt, "unit": "queries/s", "ms": dt * 1e3, "k": k, "n_keys": n, "n_queries": nq,
            "fallback_rows": int(nfb), "pipeline_tflops": flops / dt / 1e12,
            "roofline": {"kernel": "k_cand (v_mfma_f32_16x16x32_f16 scores + fused candidate filter), "
@@ -303,12 +306,14 @@ def run_cosine_topk(cpu_baseline=True, trained=None):
     g.manual_seed(7)
     Wu = torch.randn(350_000, 128, generator=g, device="cuda") * 0.05
     Wa = torch.randn(18_000, 128, generator=g, device="cuda") * 0.05
-    out["anime_18k_allpairs_top100"] = _cosine_leg(Wa, 18_000, 100, cpu_baseline)
+    out["anime_18k_allpairs_top100"] = _cosine_leg(Wa, 18_000, 100, cpu_baseline,
+                                                   traffic_name=("cosine_topk_18k_k100", 18_000))
     out["users_350k_allpairs_top100"] = _cosine_leg(Wu, 350_000, 100, cpu_baseline, reps=2,
-                                                    traffic_name="cosine_topk_k100")
+                                                    traffic_name=("cosine_topk_k100", 65_536))
     out["anime_18k_allpairs_top10"] = _cosine_leg(Wa, 18_000, 10, False)
-    out["users_350k_allpairs_top10"] = _cosine_leg(Wu, 350_000, 10, False, reps=2)
-    out["users_350k_keys_65536q_top100"] = _cosine_leg(Wu, 65_536, 100, False, traffic_name="cosine_topk_k100",
+    out["users_350k_allpairs_top10"] = _cosine_leg(Wu, 350_000, 10, False, reps=2,
+                                                   traffic_name=("cosine_topk_k10", 65_536))
+    out["users_350k_keys_65536q_top100"] = _cosine_leg(Wu, 65_536, 100, False, traffic_name=("cosine_topk_k100", 65_536),
                                                        slice_note="one 65 536-query slice of the all-pairs job")
     del Wu, Wa
     torch.cuda.empty_cache()
@@ -471,7 +476,9 @@ def run_predict_topk(cpu_baseline=True):
            "roofline": {"kernel": "k_cand<masked> (f16 MFMA cosine + watched mask + candidate filter), %d launches; "
                                   "18 k keys = 141 tiles only: ~60 appends per tile-wave, launch-bound" % cand_launches,
                         "bound": "mfma", "achieved": tfk, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": tfk / MFMA_F16_PEAK_TFLOPS, "kernel_ms": cand_ms, "traffic": None}}
+                        "frac": tfk / MFMA_F16_PEAK_TFLOPS, "kernel_ms": cand_ms,
+                        # scripts/time_predict_topk.py calls the op twice: all k_cand launches of ONE call
+                        "traffic": pmc_traffic("ptk", ["k_cand<0, 8, true>"], source="anirec_topk_mfma.hip", calls=2)}}
     if cpu_baseline:
         from oracle import c_oracle
         nc = 256

@@ -13,6 +13,9 @@ NAMES = {"train": "train_s109m", "topk100": "cosine_topk_k100", "topk10": "cosin
          "topk18k": "cosine_topk_18k_k100", "pgrid": "pgrid", "ptk": "ptk", "ingest": "ingest", "recs": "recs"}
 
 
+NCALLS = {"topk100": 3, "topk10": 3, "topkall": 3, "topk18k": 3, "pgrid": 2, "ptk": 2, "ingest": 3}   # op calls per script run
+
+
 def blob(path):        # `git hash-object`
     data = open(path, "rb").read()
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
@@ -34,6 +37,20 @@ for w in works:
                 wr = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
                 wr.writeheader()
                 wr.writerows(rows)
+    # what the profiled script printed, and per-kernel sums of the LAST call it made (the earlier ones warm up)
+    tr = glob.glob(base + "_stats/*kernel_trace.csv")
+    log = base + "_stats.log"
+    if tr and w in NCALLS:
+        rows = sorted((r for r in csv.DictReader(open(tr[0])) if "anirec" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+        by = defaultdict(list)
+        for r in rows:
+            by[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        last = {k: {"launches_per_call": len(v) // NCALLS[w], "sum_us_last_call": round(sum(v[-(len(v) // NCALLS[w]):]), 1)}
+                for k, v in by.items() if len(v) % NCALLS[w] == 0}
+        lines = [l.rstrip() for l in open(log)] if os.path.exists(log) else []
+        lines = [l for l in lines if l and not l.startswith(("W2", "E2", "I2", "/opt/amdgpu"))]
+        json.dump({"workload": name, "calls_in_script": NCALLS[w], "kernel_trace_last_call": last, "script_stdout": lines},
+                  open(os.path.join(ROOT, "profiles", "%s_%s_last_call.json" % (rnd, name)), "w"), indent=1)
     out = defaultdict(dict)
     for cn, sub, mul in (("FETCH_SIZE", "fetch", 2048.0), ("WRITE_SIZE", "write", 1024.0)):
         f = glob.glob(base + "_%s/*counter_collection.csv" % sub)

@@ -14,3 +14,7 @@ for n, nq in cfgs:
     t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     fl = 2.0 * nq * n * 128
     print("mfma k=%d n=%d nq=%d: %.2f ms  %.1f TFLOP/s  %.0f queries/s  fallback=%d" % (K, n, nq, dt * 1e3, fl / dt / 1e12, nq / dt, out[2]))
+    # the same measurement bench.py's roofline uses (HIP events around the k_cand launches, on their stream), in
+    # THIS process: under `rocprofv3 --kernel-trace --stats` it can be held against the trace of the same call
+    ops.topk_mfma_timing(True); fn(); ms, nl = ops.topk_mfma_timing(False)
+    print("k_cand by HIP events, third call: %.3f ms over %d launches = %.1f TFLOP/s" % (ms, nl, fl / ms / 1e9))
