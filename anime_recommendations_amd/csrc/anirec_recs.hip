@@ -243,52 +243,60 @@ constexpr int kRecsMaxOut = 256;
 // turned into (count, best, anime) entries.  (The first version wrote a 2-byte key per anime to LDS and walked
 // the 18 k of them four times: 69 us per query, 0.046 of the HBM rate of the 11 bit rows it reads.)
 //
-// gt / eq masks of the 6-plane numbers of a word against the scalar v
-__device__ __forceinline__ void cmp_planes(const uint32_t (&pl)[6], uint32_t v, uint32_t &gt, uint32_t &eq) {
+// gt / eq masks of the kP-plane numbers of a word against the scalar v
+template <int kP>
+__device__ __forceinline__ void cmp_planes(const uint32_t (&pl)[kP], uint32_t v, uint32_t &gt, uint32_t &eq) {
   gt = 0u;
   eq = ~0u;
 #pragma unroll
-  for (int p = 5; p >= 0; --p) {
+  for (int p = kP - 1; p >= 0; --p) {
     const uint32_t vb = ((v >> p) & 1u) ? ~0u : 0u;
     gt |= eq & pl[p] & ~vb;
     eq &= ~(pl[p] ^ vb);
   }
 }
-__device__ __forceinline__ uint32_t plane_value(const uint32_t (&pl)[6], int b) {
+template <int kP>
+__device__ __forceinline__ uint32_t plane_value(const uint32_t (&pl)[kP], int b) {
   uint32_t v = 0;
 #pragma unroll
-  for (int p = 0; p < 6; ++p) v |= ((pl[p] >> b) & 1u) << p;
+  for (int p = 0; p < kP; ++p) v |= ((pl[p] >> b) & 1u) << p;
   return v;
 }
+// sum of `n` over the workgroup's 256 lanes, the same value in every lane: a wave sum, four LDS words, ONE barrier
+// (the caller alternates between two sets of words, so the next sum may start before every wave has read this one)
+__device__ __forceinline__ int block_total(int n, int *slot4) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o, 64);
+  if ((threadIdx.x & 63) == 0) slot4[threadIdx.x >> 6] = n;
+  __syncthreads();
+  return slot4[0] + slot4[1] + slot4[2] + slot4[3];
+}
 
-template <int kR>
+// kR words per lane, kP bit planes per number (4 while k_sim <= 15: the carry chains and comparators are
+// what the kernel spends its time on)
+template <int kR, int kP>
 __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
   __shared__ uint32_t win[kRecsMaxOut];  // winners: count (7 bits) | 63 - best (8 bits) | anime (17 bits)
-  __shared__ int hist[kRecsMaxSim + 1], hist2[kRecsMaxSim + 1];
   __shared__ int sims[kRecsMaxSim];
-  __shared__ int sh_cut, sh_room, sh_cut_b, sh_room2, sh_scan, n_win;
-  __shared__ int wsum[4];
+  __shared__ int n_win;
+  __shared__ int wsum[4], tot[2][4];
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int qu = a.query[q];
   if (tid < a.k_sim) {
     const int su = a.sim[(size_t)q * a.k_sim + tid];
     sims[tid] = (su < 0 || su >= a.n_users) ? -1 : su;
   }
-  for (int c = tid; c <= kRecsMaxSim; c += 256) {
-    hist[c] = 0;
-    hist2[c] = 0;
-  }
   if (tid == 0) n_win = 0;
   __syncthreads();
 
-  uint32_t cp[kR][6], bp[kR][6], ok[kR];
+  uint32_t cp[kR][kP], bp[kR][kP], ok[kR];
   {
     uint32_t seen[kR];
 #pragma unroll
     for (int r = 0; r < kR; ++r) {
       seen[r] = 0u;
 #pragma unroll
-      for (int p = 0; p < 6; ++p) cp[r][p] = 0u, bp[r][p] = 0u;
+      for (int p = 0; p < kP; ++p) cp[r][p] = 0u, bp[r][p] = 0u;
     }
     // the words of kB similar users are requested together (an empty slot adds zeros): a workgroup's 11 rows are
     // scattered over the 350 k-user bit matrix, so the loop is bound by how many row reads are in flight
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
       for (int r = 0; r < kR; ++r) {
         uint32_t carry = bits[r];
 #pragma unroll
-        for (int p = 0; p < 6; ++p) {
+        for (int p = 0; p < kP; ++p) {
           const uint32_t t = cp[r][p] & carry;
           cp[r][p] ^= carry;
           carry = t;
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
         const uint32_t fresh = bits[r] & ~seen[r];
         seen[r] |= bits[r];
 #pragma unroll
-        for (int p = 0; p < 6; ++p)
+        for (int p = 0; p < kP; ++p)
           if ((j >> p) & 1) bp[r][p] |= fresh;
       }
       }
@@ -337,81 +345,86 @@ __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
       ok[r] = seen[r] & ~own & valid;
     }
   }
-  // level 1: histogram of counts -> the count value `cut` at which the top n_recs end.  Summed over the wave
-  // before it goes to LDS: most candidates have count 1, and 256 lanes adding to one LDS word serialise.
-  for (int c = 1; c <= a.k_sim; ++c) {
+  // level 1: the count value `cut` at which the top n_recs end = the largest c with T(c) >= n_recs, where
+  // T(c) = #{candidates with count >= c} falls with c: a binary search of block-wide popcounts, every lane
+  // following the same path (no serial walk over a histogram).  cut == 0: fewer than n_recs candidates, all taken.
+  int step = 0;
+  auto count_ge = [&](int c) {  // T(c), c >= 1
     int n = 0;
 #pragma unroll
     for (int r = 0; r < kR; ++r) {
       uint32_t gt, eq;
-      cmp_planes(cp[r], (uint32_t)c, gt, eq);
-      n += __popc(eq & ok[r]);
+      cmp_planes<kP>(cp[r], (uint32_t)(c - 1), gt, eq);
+      n += __popc(gt & ok[r]);
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o, 64);
-    if (lane == 0 && n) atomicAdd(&hist[c], n);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int cum = 0, c = a.k_sim;
-    for (; c >= 1; --c) {
-      if (cum + hist[c] >= a.n_recs) break;
-      cum += hist[c];
+    return block_total(n, tot[step++ & 1]);
+  };
+  int cut = 0, above = 0;  // above = T(cut + 1): candidates with count > cut
+  {
+    int lo = 0, hi = a.k_sim + 1;  // T(lo) >= n_recs (T(0) = everything), T(hi) < n_recs (T(k_sim + 1) = 0)
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      const int t = count_ge(mid);
+      if (t >= a.n_recs) {
+        lo = mid;
+      } else {
+        hi = mid;
+        above = t;
+      }
     }
-    sh_cut = c;                // counts > cut are all taken (cut == 0: fewer than n_recs candidates, all taken)
-    sh_room = a.n_recs - cum;  // entries still to take among those with count == cut
+    cut = lo;
   }
-  __syncthreads();
-  const int cut = sh_cut;
-  // level 2: among count == cut, histogram of the best similar-user rank -> rank `cut_b`
-  uint32_t sure[kR], atcut[kR], any_cut = 0u;
+  const int room = a.n_recs - above;  // entries still to take among those with count == cut
+  // level 2: among count == cut, the best similar-user rank `cut_b` at which they end = the smallest b with
+  // B(b) = #{count == cut, best <= b} >= room; those with best < cut_b are taken, of those at cut_b the first room2
+  uint32_t sure[kR], atcut[kR];
 #pragma unroll
   for (int r = 0; r < kR; ++r) {
     uint32_t gt, eq;
-    cmp_planes(cp[r], (uint32_t)cut, gt, eq);
+    cmp_planes<kP>(cp[r], (uint32_t)cut, gt, eq);
     sure[r] = cut == 0 ? ok[r] : (gt & ok[r]);
     atcut[r] = cut == 0 ? 0u : (eq & ok[r]);
-    any_cut |= atcut[r];
   }
-  if (__ballot(any_cut != 0u)) {
-    for (int b = 0; b < a.k_sim; ++b) {
+  int cut_b = 0, room2 = 0;
+  bool scan = false;
+  if (cut > 0) {
+    auto best_le = [&](int b) {
       int n = 0;
 #pragma unroll
       for (int r = 0; r < kR; ++r) {
         uint32_t g2, e2;
-        cmp_planes(bp[r], (uint32_t)b, g2, e2);
-        n += __popc(e2 & atcut[r]);
+        cmp_planes<kP>(bp[r], (uint32_t)b, g2, e2);
+        n += __popc(~g2 & atcut[r]);
       }
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o, 64);
-      if (lane == 0 && n) atomicAdd(&hist2[b], n);
-    }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int cum = 0, r = 0;
-    if (cut > 0) {
-      for (; r < a.k_sim; ++r) {
-        if (cum + hist2[r] >= sh_room) break;
-        cum += hist2[r];
+      return block_total(n, tot[step++ & 1]);
+    };
+    int lo = -1, hi = a.k_sim - 1, below = 0, upto = -1;  // B(lo) < room, B(hi) >= room (B(k_sim - 1) = all of them)
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      const int t = best_le(mid);
+      if (t >= room) {
+        hi = mid;
+        upto = t;
+      } else {
+        lo = mid;
+        below = t;
       }
     }
-    sh_cut_b = r;               // best rank < cut_b: taken; == cut_b: the first `room2` in anime-index order
-    sh_room2 = sh_room - cum;
-    sh_scan = (cut > 0 && r < a.k_sim && hist2[r] > sh_room - cum) ? 1 : 0;  // more ties than room: order matters
+    if (upto < 0) upto = best_le(hi);  // hi never moved
+    cut_b = hi;
+    room2 = room - below;
+    scan = upto - below > room2;  // more ties at (cut, cut_b) than room: the anime index decides
   }
-  __syncthreads();
-  const int cut_b = sh_cut_b, room2 = sh_room2;
   // level 3: exactly min(n_recs, #candidates) winners
   uint32_t tie[kR];
 #pragma unroll
   for (int r = 0; r < kR; ++r) {
     uint32_t g2, e2;
-    cmp_planes(bp[r], (uint32_t)cut_b, g2, e2);
+    cmp_planes<kP>(bp[r], (uint32_t)cut_b, g2, e2);
     sure[r] |= atcut[r] & ~g2 & ~e2;  // count == cut and best < cut_b
     tie[r] = atcut[r] & e2;
   }
-  if (sh_scan) {  // the first room2 ties in anime-index order: words ascend with r, then with the lane
+  if (scan) {  // the first room2 ties in anime-index order: words ascend with r, then with the lane
     int seen_ties = 0;
 #pragma unroll
     for (int r = 0; r < kR; ++r) {
@@ -447,7 +460,7 @@ __global__ __launch_bounds__(256) void k_user_recs(RecsArgs a) {
       take &= take - 1u;
       const int pos = atomicAdd(&n_win, 1);
       if (pos < kRecsMaxOut)
-        win[pos] = (plane_value(cp[r], b) << 25) | ((63u - plane_value(bp[r], b)) << 17) | (uint32_t)((r * 256 + tid) * 32 + b);
+        win[pos] = (plane_value<kP>(cp[r], b) << 25) | ((63u - plane_value<kP>(bp[r], b)) << 17) | (uint32_t)((r * 256 + tid) * 32 + b);
     }
   }
   for (int i = tid; i < a.n_recs; i += 256) {
@@ -547,20 +560,28 @@ int anirec_user_recs(const uint32_t *fav_bits, int32_t n_users, int32_t n_anime,
   a.n_recs = n_recs;
   a.out_anime = out_anime;
   a.out_count = out_count;
-  // a lane holds kR words of 32 anime in registers
+  // a lane holds kR words of 32 anime in registers, as kP bit planes
+#define ANIREC_RECS(R)                                                                              \
+  do {                                                                                              \
+    if (k_sim <= 15)                                                                                \
+      hipLaunchKernelGGL((k_user_recs<R, 4>), dim3(nq), dim3(256), 0, (hipStream_t)stream, a);      \
+    else                                                                                            \
+      hipLaunchKernelGGL((k_user_recs<R, 6>), dim3(nq), dim3(256), 0, (hipStream_t)stream, a);      \
+  } while (0)
   if (wwords <= 256) {
-    hipLaunchKernelGGL(k_user_recs<1>, dim3(nq), dim3(256), 0, (hipStream_t)stream, a);
+    ANIREC_RECS(1);
   } else if (wwords <= 2 * 256) {
-    hipLaunchKernelGGL(k_user_recs<2>, dim3(nq), dim3(256), 0, (hipStream_t)stream, a);
+    ANIREC_RECS(2);
   } else if (wwords <= 3 * 256) {
-    hipLaunchKernelGGL(k_user_recs<3>, dim3(nq), dim3(256), 0, (hipStream_t)stream, a);  // 17 560 anime: 549 words
+    ANIREC_RECS(3);  // 17 560 anime: 549 words
   } else if (wwords <= 4 * 256) {
-    hipLaunchKernelGGL(k_user_recs<4>, dim3(nq), dim3(256), 0, (hipStream_t)stream, a);
+    ANIREC_RECS(4);
   } else if (wwords <= 8 * 256) {
-    hipLaunchKernelGGL(k_user_recs<8>, dim3(nq), dim3(256), 0, (hipStream_t)stream, a);
+    ANIREC_RECS(8);
   } else {
-    hipLaunchKernelGGL(k_user_recs<16>, dim3(nq), dim3(256), 0, (hipStream_t)stream, a);  // n_anime < 2^17
+    ANIREC_RECS(16);  // n_anime < 2^17
   }
+#undef ANIREC_RECS
   return (int)hipGetLastError();
 }
 

@@ -537,9 +537,9 @@ def run_user_recs(cpu_baseline=True):
                           "roofline": {"kernel": "k_rec_count/scatter/percentile/favbits (5 launches)", "bound": "hbm",
                                        "achieved": fav_bytes / dt_f / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": fav_bytes / dt_f / 1e9 / HBM_PEAK_GBS, "traffic": None}},
-           "roofline": {"kernel": "k_user_recs<3> (one workgroup per query: 11 bit rows of 2.25 KB -> bit-sliced counts in registers -> top-10)",
+           "roofline": {"kernel": "k_user_recs<3, 4> (one workgroup per query: 11 bit rows of 2.25 KB -> bit-sliced counts in registers, block-wide binary searches for the cut -> top-10)",
                         "bound": "hbm", "achieved": rec_bytes / dt_r / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": rec_bytes / dt_r / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("recs", "k_user_recs<3>", source="anirec_recs.hip")}}
+                        "frac": rec_bytes / dt_r / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("recs", "k_user_recs<3, 4>", source="anirec_recs.hip")}}
     if cpu_baseline:
         from oracle import recs_oracle
         nu_s = 2_000                                       # users 0..1999 of the same table
