@@ -58,35 +58,51 @@ __global__ __launch_bounds__(256) void k_rec_count(const int32_t *user, int64_t 
     }
   }
 }
-// exclusive scan of the per-user counts -> row pointers: one workgroup walks coalesced tiles of 1024
+// exclusive scan of the per-user counts -> row pointers: one workgroup walks coalesced blocks of kScanT tiles of
+// 1024 counts; the tiles of a block are scanned independently in registers and stitched with one barrier pair
+constexpr int kScanT = 8;
 __global__ __launch_bounds__(1024) void k_rec_scan(const int32_t *cnt, int n_users, int64_t *ptr, int64_t *cursor) {
-  __shared__ long long wtot[16];
-  __shared__ long long carry_s;
+  __shared__ long long wtot[2][kScanT][16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < n_users; base += 1024) {
-    const int i = base + threadIdx.x;
-    const long long v = i < n_users ? cnt[i] : 0;
-    long long inc = v;
+  long long carry = 0;  // total of everything before this block, the same in every lane
+  int it = 0;
+  for (int base = 0; base < n_users; base += 1024 * kScanT, ++it) {
+    long long v[kScanT], inc[kScanT];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const long long y = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += y;
+    for (int k = 0; k < kScanT; ++k) {
+      const int i = base + k * 1024 + threadIdx.x;
+      v[k] = i < n_users ? cnt[i] : 0;
     }
-    if (lane == 63) wtot[w] = inc;
-    __syncthreads();
-    long long off = carry_s;
-    for (int x = 0; x < w; ++x) off += wtot[x];
-    if (i < n_users) {
-      ptr[i] = off + inc - v;
-      cursor[i] = off + inc - v;
+#pragma unroll
+    for (int k = 0; k < kScanT; ++k) {
+      inc[k] = v[k];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const long long y = __shfl_up(inc[k], o, 64);
+        if (lane >= o) inc[k] += y;
+      }
+      if (lane == 63) wtot[it & 1][k][w] = inc[k];
     }
-    __syncthreads();
-    if (threadIdx.x == 1023) carry_s = off + inc;
-    __syncthreads();
+    __syncthreads();  // (the other half of wtot is what the previous block's readers may still hold)
+    long long off = carry;
+#pragma unroll
+    for (int k = 0; k < kScanT; ++k) {
+      long long tile = 0, before = 0;
+      for (int x = 0; x < 16; ++x) {
+        const long long t = wtot[it & 1][k][x];
+        before += x < w ? t : 0;
+        tile += t;
+      }
+      const int i = base + k * 1024 + threadIdx.x;
+      if (i < n_users) {
+        ptr[i] = off + before + inc[k] - v[k];
+        cursor[i] = off + before + inc[k] - v[k];
+      }
+      off += tile;
+    }
+    carry = off;
   }
-  if (threadIdx.x == 0) ptr[n_users] = carry_s;
+  if (threadIdx.x == 0) ptr[n_users] = carry;
 }
 // CSR payload: a straight copy when the table is grouped by user, an atomic-cursor scatter otherwise
 __global__ __launch_bounds__(256) void k_rec_scatter(const int32_t *user, const double *rating, int64_t n, int n_users,
