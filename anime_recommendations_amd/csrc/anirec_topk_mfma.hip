@@ -31,6 +31,12 @@
 //     row 1 429 -> 530, k_refresh 0.58 -> 0.23 ms, k_cand 7.06 -> 6.82 ms — the cost of the filter is how often
 //     a 16x16 block holds ANY candidate (~18 % of the blocks at k = 100, set by the k-th-best window itself),
 //     not how many candidates are appended; and ~4e-4 of the rows then need the exact fallback.
+//   * a ring of 4 key tiles (128 KB of LDS) with a LAGGED barrier (at its sync point of tile t a wave waits, on
+//     LDS counters, for every wave to have passed the sync point of tile t-1, so a wave that met candidates does
+//     not stall the other seven): bit-identical lists, cycles per wave and tile 3 892 -> 3 644 (-6 %), wait at the
+//     sync point 752 -> 632 — and the same wall time to 1 % in interleaved same-box rounds (k = 100: 6.43-6.49 ms
+//     against 6.41-6.57; k = 10: 5.21-5.24 against 5.17-5.22): the chip answers fewer cycles with a lower clock.
+//     The kernel is POWER-limited; only less energy per MFMA would make it faster.
 //   In-kernel stamps: 3 271 (k = 10) / 4 066 (k = 100) cycles per wave and tile against an MFMA floor of 2 048
 //   (two waves per SIMD); vmcnt wait at the tile barrier 42-63 cycles (the candidate stores do not stall it),
 //   barrier skew 470-790.  Without any filter the loop runs at 1.37 PFLOP/s on that box (0.55 of the peak).
