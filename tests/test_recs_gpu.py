@@ -45,6 +45,37 @@ def test_thresholds_and_favourite_sets_match_numpy(grid, pct, grouped):
         assert got == fav_o[uu], uu
 
 
+@pytest.mark.parametrize("kind", ["grid", "random", "negative", "two_values"])
+def test_thresholds_for_long_and_boundary_segments(kind):
+    """Segment lengths around the kernel's register path (<= 1 024 ratings, keys held in registers, passes whose
+    digit is shared by every remaining key skipped) and its streaming path (longer): 1, 63..65, 1 023..1 025, 3 000."""
+    from anime_recommendations_amd import recs
+    rng = np.random.default_rng(41)
+    sizes = np.array([1, 2, 63, 64, 65, 127, 128, 129, 511, 1023, 1024, 1025, 1500, 3000, 0, 7])
+    n_users, n_anime = len(sizes), 3000
+    u = np.repeat(np.arange(n_users), sizes).astype(np.int32)
+    a = np.concatenate([rng.choice(n_anime, s, replace=False) for s in sizes]).astype(np.int32)
+    if kind == "grid":
+        r = rng.integers(0, 11, len(u)) / 10
+    elif kind == "random":
+        r = rng.random(len(u))
+    elif kind == "negative":                                 # sign and exponent bytes vary, incl. -0.0 / 0.0
+        r = rng.normal(0, 1e3, len(u)) * (rng.random(len(u)) > .2)
+        r[::17] = -0.0
+    else:
+        r = np.where(rng.random(len(u)) < .5, 0.7, 0.7000000000000001)
+    for pct in (80, 37.5):
+        thr_o, fav_o = orc.favourites(u, a, r.astype(np.float64), n_users, pct)
+        fav, thr = recs.user_favourites(torch.as_tensor(u).cuda(), torch.as_tensor(a).cuda(),
+                                        torch.as_tensor(r.astype(np.float64)).cuda(), n_users, n_anime, pct)
+        thr = thr.cpu().numpy()
+        ok = ~np.isnan(thr_o)
+        assert np.array_equal(np.isnan(thr), ~ok)
+        # bit for bit, except the sign of a zero: -0.0 == 0.0 to numpy's partition, so which of the two it returns
+        # is an accident of its introselect; the kernel returns +0.0
+        assert np.array_equal((thr[ok] + 0.0).view(np.uint64), (thr_o[ok] + 0.0).view(np.uint64)), (kind, pct)
+
+
 def test_user_recs_counts_and_order():
     from anime_recommendations_amd import recs
     n_users, n_anime, k_sim, n_recs = 400, 900, 10, 12
