@@ -37,6 +37,11 @@
 //     sync point 752 -> 632 — and the same wall time to 1 % in interleaved same-box rounds (k = 100: 6.43-6.49 ms
 //     against 6.41-6.57; k = 10: 5.21-5.24 against 5.17-5.22): the chip answers fewer cycles with a lower clock.
 //     The kernel is POWER-limited; only less energy per MFMA would make it faster.
+//   * exploiting the symmetry of the all-pairs job (score(q, k) also is a candidate for row k: half the MFMAs):
+//     emulated by adding a column-direction test (one compare per 16x16 block against the key rows' thresholds,
+//     then per-register tests and an LDS-staged append on a hit) to every tile of the present kernel — k_cand
+//     6.6 -> 13.5 ms at k = 100 and 5.3 -> 8.2 ms at k = 10, i.e. at best 0.98x / 1.29x after halving the tiles.
+//     Not built: the second filter costs what the saved MFMAs are worth.
 //   In-kernel stamps: 3 271 (k = 10) / 4 066 (k = 100) cycles per wave and tile against an MFMA floor of 2 048
 //   (two waves per SIMD); vmcnt wait at the tile barrier 42-63 cycles (the candidate stores do not stall it),
 //   barrier skew 470-790.  Without any filter the loop runs at 1.37 PFLOP/s on that box (0.55 of the peak).
