@@ -149,6 +149,8 @@ def run_single(workload, steps, warmup, batch, use_graph=True, cpu_baseline=True
     traffic = None
     if workload == "s109m" and batch == 10_000:
         traffic = pmc_traffic("train_s109m", "k_adam<true>", source="anirec_train.hip")
+    elif workload == "s7m" and batch == 10_000:      # cache-resident tables: the plain (not non-temporal) kernel
+        traffic = pmc_traffic("train_s7m", "k_adam<false>", source="anirec_train.hip")
     step_bytes = (FWD_BYTES_PER_RATING + BWD_BYTES_PER_RATING) * batch + adam_bytes
     out = {
         "value": steps * batch / dt,
@@ -536,7 +538,10 @@ def run_user_recs(cpu_baseline=True):
            "favourites": {"ms": dt_f * 1e3, "ratings_per_s": n / dt_f,
                           "roofline": {"kernel": "k_rec_count/scatter/percentile/favbits (5 launches)", "bound": "hbm",
                                        "achieved": fav_bytes / dt_f / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": fav_bytes / dt_f / 1e9 / HBM_PEAK_GBS, "traffic": None}},
+                                       "frac": fav_bytes / dt_f / 1e9 / HBM_PEAK_GBS,
+                                       "traffic": pmc_traffic("recs", {"k_rec_count": 1, "k_rec_scan": 1, "k_rec_scatter": 1,
+                                                                       "k_rec_percentile": 1, "k_rec_favbits": 1},
+                                                              source="anirec_recs.hip")}},
            "roofline": {"kernel": "k_user_recs<3, 4> (one workgroup per query: 11 bit rows of 2.25 KB -> bit-sliced counts in registers, block-wide binary searches for the cut -> top-10)",
                         "bound": "hbm", "achieved": rec_bytes / dt_r / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": rec_bytes / dt_r / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("recs", "k_user_recs<3, 4>", source="anirec_recs.hip")}}

@@ -13,6 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 for W in "$@"; do
   case $W in
     train)   CMD="$ROOT/bench.py --no-also --no-cpu-baseline --steps 96 --warmup 32";;
+    train7m) CMD="$ROOT/bench.py --workload s7m --no-also --no-cpu-baseline --steps 96 --warmup 32";;
     topk100) CMD="$ROOT/scripts/time_topk.py 350000 65536 100";;
     topk10)  CMD="$ROOT/scripts/time_topk.py 350000 65536 10";;
     topkall) CMD="$ROOT/scripts/time_topk.py 350000 350000 100";;

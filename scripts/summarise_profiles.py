@@ -9,7 +9,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd, works = sys.argv[1], sys.argv[2:]
-NAMES = {"train": "train_s109m", "topk100": "cosine_topk_k100", "topk10": "cosine_topk_k10", "topkall": "cosine_topk_allpairs_k100",
+NAMES = {"train": "train_s109m", "train7m": "train_s7m", "topk100": "cosine_topk_k100", "topk10": "cosine_topk_k10", "topkall": "cosine_topk_allpairs_k100",
          "topk18k": "cosine_topk_18k_k100", "pgrid": "pgrid", "ptk": "ptk", "ingest": "ingest", "recs": "recs"}
 
 
