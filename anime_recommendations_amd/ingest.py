@@ -55,14 +55,20 @@ def _bound(t):
     return max(int(t.max()) + 1, 1) if t.numel() else 1
 
 
+def _aligned(t):
+    """Contiguous and 16-byte aligned (the kernels read four rows per lane): a sliced view is copied."""
+    t = t.contiguous()
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
 def preprocess_columns(cols, num_reviews, drop_unwatched=False, drop_plan=False, drop_half_watched=False):
     """drop_useless (+ drop_half_watched) + scale_ratings on device columns.
     Returns a dict of device tensors with the surviving rows in their original order."""
     _need_gpu()
     lib = _lib.load()
-    u, a = cols["user_id"].contiguous(), cols["anime_id"].contiguous()
-    r = cols["rating"].contiguous()
-    s, e = cols["watching_status"].contiguous(), cols["watched_episodes"].contiguous()
+    u, a = _aligned(cols["user_id"]), _aligned(cols["anime_id"])
+    r = _aligned(cols["rating"])
+    s, e = _aligned(cols["watching_status"]), _aligned(cols["watched_episodes"])
     assert u.dtype == a.dtype == s.dtype == e.dtype == torch.int32 and r.dtype == torch.float64
     n = int(u.numel())
     dev = u.device
@@ -106,7 +112,7 @@ def encode_ids(ids):
     """``Series.unique()`` encoding on the GPU: (index int32 [n], uniques int32 [n_unique])."""
     _need_gpu()
     lib = _lib.load()
-    ids = ids.contiguous()
+    ids = _aligned(ids)
     assert ids.dtype == torch.int32
     n = int(ids.numel())
     dev = ids.device

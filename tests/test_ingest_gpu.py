@@ -188,3 +188,29 @@ def test_encode_frame_gpu_equals_host_encode_frame():
         for f in ("user", "anime", "rating", "user_ids", "anime_ids"):
             a, b = getattr(got, f), getattr(ref, f)
             assert a.dtype == b.dtype and np.array_equal(a, b), f
+
+
+def test_unaligned_views_are_accepted_by_the_wrappers_and_rejected_by_the_c_entry():
+    """The kernels read 16 bytes at a time: the C entry points return ANIREC_EINVAL for a misaligned column, the
+    Python wrappers copy a sliced view first."""
+    import ctypes as C
+    from anime_recommendations_amd import _lib, ingest
+    df = _raw_frame(20_001, 90, 70, seed=3, nulls=False)
+    cols = ingest.frame_to_columns(df)
+    view = {k: v[1:] for k, v in cols.items()}               # 4 / 8 bytes past an aligned address
+    assert any(v.data_ptr() % 16 for v in view.values())
+    got = ingest.preprocess_columns(view, num_reviews=20)
+    want = orc.preprocess(df.iloc[1:].reset_index(drop=True), 20)
+    np.testing.assert_array_equal(got["user_id"].cpu().numpy(), want["user_id"].to_numpy())
+    idx, uniq = ingest.encode_ids(cols["user_id"][1:])
+    want_idx, want_uniq = orc.encode(pd.Series(cols["user_id"][1:].cpu().numpy()))
+    np.testing.assert_array_equal(idx.cpu().numpy(), want_idx)
+    lib = _lib.load()
+    ids = cols["user_id"]
+    n = ids.numel() - 1
+    ws = torch.empty(int(lib.anirec_ingest_encode_workspace_bytes(n, 1000)), dtype=torch.uint8, device="cuda")
+    out = torch.empty(n + 4, dtype=torch.int32, device="cuda")
+    z = torch.zeros(4, dtype=torch.int64, device="cuda")
+    rc = lib.anirec_ingest_encode(C.c_void_p(ids.data_ptr() + 4), n, 1000, _lib.ptr(out), _lib.ptr(out), _lib.ptr(z),
+                                  _lib.ptr(z[2:]), _lib.ptr(ws), ws.numel(), None)
+    assert rc == _lib.EINVAL if hasattr(_lib, "EINVAL") else rc < 0
