@@ -42,6 +42,12 @@
 //     then per-register tests and an LDS-staged append on a hit) to every tile of the present kernel — k_cand
 //     6.6 -> 13.5 ms at k = 100 and 5.3 -> 8.2 ms at k = 10, i.e. at best 0.98x / 1.29x after halving the tiles.
 //     Not built: the second filter costs what the saved MFMAs are worth.
+//   Where the k = 100 time goes (ANIREC_TOPK_DEBUG=16, same 65 536-query slice, same box): no filter at all 4.2 ms;
+//   the filter with thresholds nothing passes 4.4-4.5 ms; ONE launch with the FINAL thresholds handed in (a row
+//   appends only its k + window candidates) 5.0-5.6 ms; the real schedule — 11 launches, each threshold the k-th
+//   best of the keys seen so far, ~950 appends per row instead of ~110 — 6.6 ms.  The extra ~850 appends are what
+//   an exact sequential top-k pays (k (g - 1) per super-step of growth g, k ln(n / n0) in the limit g -> 1); a
+//   conservative threshold from a key sample does not beat it (measured above, and by the same arithmetic).
 //   In-kernel stamps: 3 271 (k = 10) / 4 066 (k = 100) cycles per wave and tile against an MFMA floor of 2 048
 //   (two waves per SIMD); vmcnt wait at the tile barrier 42-63 cycles (the candidate stores do not stall it),
 //   barrier skew 470-790.  Without any filter the loop runs at 1.37 PFLOP/s on that box (0.55 of the peak).
@@ -228,6 +234,7 @@ __global__ __launch_bounds__(64) void k_refresh(CandArgs a) {
 // kMask: a candidate is dropped at append time when its bit in the query's own mask row is set (the
 // "already watched" set of model_recs); the mask words reach a wave-private LDS image by LDS-DMA two tiles ahead.
 template <int kDbg, int kWaves, bool kMask = false>  // kDbg 0: product; 1: no filter (timing only); 2: count appends; 4: stamps
+// (host-side mode 16: after the product run, one launch over all keys with the final / with unreachable thresholds)
 __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
   constexpr int kBM = 32 * kWaves;
   constexpr int kDma = 32 / kWaves;  // LDS-DMA instructions per wave per key tile (4 key rows each)
@@ -758,6 +765,35 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
       g_cand_ms += ms;
       (void)hipEventDestroy(timed[i]);
       (void)hipEventDestroy(timed[i + 1]);
+    }
+  }
+  if (mode == 16 && !masked) {
+    // diagnostic: ONE launch over all keys with the FINAL thresholds (what the filter costs when a row only ever
+    // sees its k + window candidates), and one with thresholds nothing passes (filter without any hit)
+    for (int pass = 0; pass < 2; ++pass) {
+      (void)hipMemsetAsync(ca.cnt, 0, (size_t)nq * 4, s);
+      if (pass == 1) {
+        std::vector<float> big((size_t)nq, 2.0f);
+        (void)hipMemcpyAsync(ca.theta, big.data(), (size_t)nq * 4, hipMemcpyHostToDevice, s);
+      }
+      ca.tile0 = 0;
+      ca.tile1 = ntiles;
+      hipEvent_t e0, e1;
+      (void)hipEventCreate(&e0);
+      (void)hipEventCreate(&e1);
+      (void)hipEventRecord(e0, s);
+      if (wide)
+        hipLaunchKernelGGL((k_cand<0, 8, false>), grid, block, 0, s, ca);
+      else
+        hipLaunchKernelGGL((k_cand<0, 4, false>), grid, block, 0, s, ca);
+      (void)hipEventRecord(e1, s);
+      (void)hipEventSynchronize(e1);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      fprintf(stderr, "[anirec topk debug] one launch over %d tiles with %s thresholds: %.3f ms\n", ntiles,
+              pass == 0 ? "the final" : "unreachable", ms);
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
     }
   }
   if (mode == 2 && !masked) {
