@@ -35,88 +35,154 @@ __device__ __forceinline__ double dkey_inv(unsigned long long o) {
 // Per-user counts.  The rating table usually arrives grouped by user (the raw / preprocessed order): a wave
 // adds one atomic per RUN of equal users among its 64 consecutive rows, and `unsorted` records whether any
 // row breaks the non-decreasing order — if none does, the table already IS the CSR payload.
+// (A lane reads 4 consecutive rows, kRecIters quads in flight: the pass is latency-bound otherwise.)
+constexpr int kRecIters = 4;
+__device__ __forceinline__ int4 ld4r(const int32_t *p, int64_t i, int64_t n, int32_t fill) {
+  if (i + 3 < n) return *reinterpret_cast<const int4 *>(p + i);
+  return make_int4(i < n ? p[i] : fill, i + 1 < n ? p[i + 1] : fill, i + 2 < n ? p[i + 2] : fill, fill);
+}
 __global__ __launch_bounds__(256) void k_rec_count(const int32_t *user, int64_t n, int n_users, int32_t *cnt,
                                                    int32_t *err, int32_t *unsorted) {
   const int lane = lane_id();
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int64_t n_round = (n + 63) / 64 * 64;  // whole waves stay converged for the shuffles
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
-    int u = i < n ? user[i] : -1;
-    if (i < n && (u < 0 || u >= n_users)) {
-      *err = 1;
-      u = -1;
+  int4 q[kRecIters];
+  int32_t prev[kRecIters];  // the row before the lane-0 quad of the wave (the order test crosses wave edges)
+  int64_t i0[kRecIters];
+#pragma unroll
+  for (int k = 0; k < kRecIters; ++k) {
+    i0[k] = (((int64_t)blockIdx.x * kRecIters + k) * 256 + threadIdx.x) * 4;
+    q[k] = ld4r(user, i0[k], n, -1);
+    prev[k] = (lane == 0 && i0[k] > 0 && i0[k] < n) ? user[i0[k] - 1] : -1;
+  }
+  bool bad = false, uns = false;
+#pragma unroll
+  for (int k = 0; k < kRecIters; ++k) {
+    int32_t v[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+    const int32_t raw3 = v[3];
+    int32_t left_raw = __shfl_up(raw3, 1, 64);  // raw ids for the order test
+    if (lane == 0) left_raw = prev[k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool live = i0[k] + j < n;
+      const int32_t before = j ? v[j - 1] : left_raw;
+      if (live && (j || lane || i0[k] > 0) && v[j] < before) uns = true;
     }
-    int left = __shfl_up(u, 1, 64);
-    if (lane == 0) left = (i > 0 && i < n) ? user[i - 1] : u;
-    if (i < n && u < left) *unsorted = 1;
-    const bool head = lane == 0 || u != __shfl_up(u, 1, 64);
-    const unsigned long long heads = __ballot(head);
-    if (head && u >= 0) {
-      const unsigned long long later = lane == 63 ? 0ULL : heads >> (lane + 1);
-      const int len = later ? __ffsll((long long)later) : 64 - lane;
-      atomicAdd(&cnt[u], len);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i0[k] + j < n && (v[j] < 0 || v[j] >= n_users)) {
+        bad = true;
+        v[j] = -1;
+      } else if (i0[k] + j >= n) {
+        v[j] = -1;
+      }
+    // one atomic per RUN of equal users: lanes whose four rows share a user are chained across the wave (a user's
+    // ~300 rows are ~78 such lanes), a lane that holds a boundary adds its own pieces
+    const bool uni = v[0] >= 0 && v[0] == v[1] && v[1] == v[2] && v[2] == v[3];
+    const int32_t key = uni ? v[0] : -2;
+    const int32_t lkey = __shfl_up(key, 1, 64);
+    const bool head = uni && (lane == 0 || lkey != key);
+    const unsigned long long brk = __ballot(head || !uni);  // lanes at which a chain of equal lanes ends
+    if (head) {
+      const unsigned long long later = lane == 63 ? 0ULL : brk >> (lane + 1);
+      const int lanes = later ? __ffsll((long long)later) : 64 - lane;
+      atomicAdd(&cnt[key], 4 * lanes);
+    }
+    if (!uni) {
+      int run = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (v[j] < 0) continue;
+        ++run;
+        if (j == 3 || v[j + 1] != v[j]) {
+          atomicAdd(&cnt[v[j]], run);
+          run = 0;
+        }
+      }
     }
   }
+  if (bad) *err = 1;
+  if (uns) *unsorted = 1;
 }
-// exclusive scan of the per-user counts -> row pointers: one workgroup walks coalesced blocks of kScanT tiles of
-// 1024 counts; the tiles of a block are scanned independently in registers and stitched with one barrier pair
-constexpr int kScanT = 8;
-__global__ __launch_bounds__(1024) void k_rec_scan(const int32_t *cnt, int n_users, int64_t *ptr, int64_t *cursor) {
-  __shared__ long long wtot[2][kScanT][16];
+// exclusive scan of the per-user counts -> row pointers, three launches: totals of tiles of 4 096 counts, a
+// one-workgroup scan of the tile totals, the tiles again with their bases
+constexpr int kRsTile = 4096;  // 256 lanes x 16 counts
+__global__ __launch_bounds__(256) void k_rec_scan_reduce(const int32_t *cnt, int n_users, long long *tsum) {
+  __shared__ long long ws[4];
+  const int base = blockIdx.x * kRsTile + threadIdx.x * 16;
+  long long sm = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) sm += base + j < n_users ? cnt[base + j] : 0;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) sm += __shfl_xor(sm, o, 64);
+  if (lane_id() == 0) ws[threadIdx.x >> 6] = sm;
+  __syncthreads();
+  if (threadIdx.x == 0) tsum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ __launch_bounds__(1024) void k_rec_scan_spine(long long *tsum, int n_tiles, int64_t *ptr, int n_users) {
+  __shared__ long long wtot[16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  long long carry = 0;  // total of everything before this block, the same in every lane
-  int it = 0;
-  for (int base = 0; base < n_users; base += 1024 * kScanT, ++it) {
-    long long v[kScanT], inc[kScanT];
+  long long carry = 0;
+  for (int base = 0; base < n_tiles; base += 1024) {
+    const int i = base + threadIdx.x;
+    const long long v = i < n_tiles ? tsum[i] : 0;
+    long long inc = v;
 #pragma unroll
-    for (int k = 0; k < kScanT; ++k) {
-      const int i = base + k * 1024 + threadIdx.x;
-      v[k] = i < n_users ? cnt[i] : 0;
+    for (int o = 1; o < 64; o <<= 1) {
+      const long long y = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += y;
     }
-#pragma unroll
-    for (int k = 0; k < kScanT; ++k) {
-      inc[k] = v[k];
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const long long y = __shfl_up(inc[k], o, 64);
-        if (lane >= o) inc[k] += y;
-      }
-      if (lane == 63) wtot[it & 1][k][w] = inc[k];
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    long long before = carry, all = 0;
+    for (int x = 0; x < 16; ++x) {
+      before += x < w ? wtot[x] : 0;
+      all += wtot[x];
     }
-    __syncthreads();  // (the other half of wtot is what the previous block's readers may still hold)
-    long long off = carry;
-#pragma unroll
-    for (int k = 0; k < kScanT; ++k) {
-      long long tile = 0, before = 0;
-      for (int x = 0; x < 16; ++x) {
-        const long long t = wtot[it & 1][k][x];
-        before += x < w ? t : 0;
-        tile += t;
-      }
-      const int i = base + k * 1024 + threadIdx.x;
-      if (i < n_users) {
-        ptr[i] = off + before + inc[k] - v[k];
-        cursor[i] = off + before + inc[k] - v[k];
-      }
-      off += tile;
-    }
-    carry = off;
+    if (i < n_tiles) tsum[i] = before + inc - v;
+    carry += all;
+    __syncthreads();
   }
   if (threadIdx.x == 0) ptr[n_users] = carry;
+}
+__global__ __launch_bounds__(256) void k_rec_scan_apply(const int32_t *cnt, int n_users, const long long *tsum,
+                                                        int64_t *ptr, int64_t *cursor) {
+  __shared__ long long ws[4];
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  const int base = blockIdx.x * kRsTile + threadIdx.x * 16;
+  long long c[16], mine = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    c[j] = base + j < n_users ? cnt[base + j] : 0;
+    mine += c[j];
+  }
+  long long inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const long long y = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += y;
+  }
+  if (lane == 63) ws[w] = inc;
+  __syncthreads();
+  long long run = tsum[blockIdx.x] + inc - mine;
+  for (int x = 0; x < w; ++x) run += ws[x];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (base + j < n_users) {
+      ptr[base + j] = run;
+      cursor[base + j] = run;
+    }
+    run += c[j];
+  }
 }
 // CSR payload: a straight copy when the table is grouped by user, an atomic-cursor scatter otherwise
 __global__ __launch_bounds__(256) void k_rec_scatter(const int32_t *user, const double *rating, int64_t n, int n_users,
                                                      int64_t *cursor, const int32_t *unsorted, double *csr_rating) {
-  const bool grouped = *unsorted == 0;
+  // grouped by user: the table already IS the CSR payload and k_rec_percentile reads it in place (out-of-range
+  // users were excluded from the counts: positions stay aligned with ptr[] only for valid tables, and err_flag
+  // reports the others)
+  if (*unsorted == 0) return;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int u = user[i];
-    if (grouped) {
-      // out-of-range users were excluded from the counts: they break neither the order test nor ptr[] only if
-      // absent, and err_flag reports them; the copy keeps positions aligned with ptr[] for valid tables
-      csr_rating[i] = rating[i];
-      continue;
-    }
     if (u < 0 || u >= n_users) continue;
     const long long p = (long long)atomicAdd((unsigned long long *)&cursor[u], 1ULL);
     csr_rating[p] = rating[i];  // order inside a user's segment is irrelevant to an order statistic
@@ -133,15 +199,33 @@ __global__ __launch_bounds__(256) void k_rec_scatter(const int32_t *user, const 
 // the passes whose digit is shared by every key still in play and adding to the histogram through one leader lane
 // per distinct digit — 1 455 us against 1 371 us for 350 k users: the kernel is VALU-issue-bound (PMC: 1 330 VALU +
 // 930 SALU instructions per user-wave), not bound by the re-reads, which hit in L2.
+// When the table is grouped by user (`*unsorted == 0`: the raw order) the wave reads the user's ratings in place (no
+// CSR copy exists) and, with `fav` given, goes on to build the user's favourite-bit row in a wave-private LDS
+// bitmap and writes the whole row with plain coalesced stores: no pass over the 109 M rows for the bits, no
+// atomics to HBM, no zero-fill of the 788 MB bit matrix (FavFuse; k_rec_favbits then returns at once).
+struct FavFuse {
+  const double *rating;    // the table's own rating column
+  const int32_t *anime;
+  const int32_t *unsorted;
+  uint32_t *fav;           // nullptr: thresholds only
+  int wwords, n_anime;
+  int32_t *err;
+};
 __global__ __launch_bounds__(256) void k_rec_percentile(const double *csr_rating, const int64_t *ptr, int n_users,
-                                                        double pct, double *thr) {
+                                                        double pct, double *thr, FavFuse f) {
   __shared__ uint32_t hist[4][256];
+  extern __shared__ uint32_t bitmaps[];  // [4][wwords] when the bits are fused
   const int lane = lane_id(), w = threadIdx.x >> 6;
   const int u = blockIdx.x * 4 + w;
   if (u >= n_users) return;  // whole wave leaves together; no block barrier below
+  const bool grouped = *f.unsorted == 0;
+  const bool fuse = grouped && f.fav != nullptr;
+  if (grouped) csr_rating = f.rating;
   const long long s0 = ptr[u], n = ptr[u + 1] - s0;
   if (n <= 0) {
     if (lane == 0) thr[u] = __longlong_as_double(0x7FF8000000000000LL);  // no ratings: NaN, no favourites
+    if (fuse)
+      for (int x = lane; x < f.wwords; x += 64) f.fav[(size_t)u * f.wwords + x] = 0u;
     return;
   }
   const double pos = (pct / 100.0) * (double)(n - 1);
@@ -221,23 +305,78 @@ __global__ __launch_bounds__(256) void k_rec_percentile(const double *csr_rating
       if (t == 0.0) r = a;  // (numpy: where(t == 0, a, ...) is implied by a + 0; kept explicit for -0.0)
     }
     thr[u] = r;
+    if (fuse) hist[w][0] = 0u, reinterpret_cast<double *>(&hist[w][2])[0] = r;  // hand the threshold to the wave
   }
+  if (!fuse) return;
+  __builtin_amdgcn_wave_barrier();
+  const double cut = reinterpret_cast<const double *>(&hist[w][2])[0];
+  uint32_t *bm = bitmaps + (size_t)w * f.wwords;
+  for (int x = lane; x < f.wwords; x += 64) bm[x] = 0u;
+  __builtin_amdgcn_wave_barrier();
+  bool bad = false;
+  for (long long i = lane; i < n; i += 64) {
+    const int a = f.anime[s0 + i];
+    if (a < 0 || a >= f.n_anime) {
+      bad = true;
+      continue;
+    }
+    if (csr_rating[s0 + i] >= cut) atomicOr(&bm[a >> 5], 1u << (a & 31));  // rating >= percentile (user_recs.py:394)
+  }
+  if (bad) *f.err = 1;
+  __builtin_amdgcn_wave_barrier();
+  for (int x = lane; x < f.wwords; x += 64) f.fav[(size_t)u * f.wwords + x] = bm[x];
 }
 
 // favourite bits: rating >= the user's own threshold (user_recs.py:394 `watched.rating >= percentile`)
+// zero-fill of the bit matrix for the atomicOr path: only a table that is NOT grouped by user needs it
+__global__ __launch_bounds__(256) void k_rec_clear(uint4 *fav16, size_t n16, const int32_t *unsorted, int fused) {
+  if (fused && *unsorted == 0) return;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+    fav16[i] = make_uint4(0u, 0u, 0u, 0u);
+}
 __global__ __launch_bounds__(256) void k_rec_favbits(const int32_t *user, const int32_t *anime, const double *rating,
                                                      int64_t n, int n_users, int n_anime, const double *thr,
-                                                     uint32_t *fav, int wwords, int32_t *err) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int u = user[i], a = anime[i];
-    if (u < 0 || u >= n_users) continue;
-    if (a < 0 || a >= n_anime) {
-      *err = 1;
-      continue;
+                                                     uint32_t *fav, int wwords, int32_t *err, const int32_t *unsorted,
+                                                     int fused) {
+  if (fused && *unsorted == 0) return;  // k_rec_percentile wrote the rows
+  constexpr int kIt = 2;
+  bool bad = false;
+  for (int64_t blk = blockIdx.x; blk * (1024 * kIt) < n; blk += gridDim.x) {
+  int4 U[kIt], A[kIt];
+  double R[kIt][4];
+  int64_t i0[kIt];
+#pragma unroll
+  for (int k = 0; k < kIt; ++k) {
+    i0[k] = ((blk * kIt + k) * 256 + threadIdx.x) * 4;
+    U[k] = ld4r(user, i0[k], n, -1);
+    A[k] = ld4r(anime, i0[k], n, 0);
+    if (i0[k] + 3 < n) {
+      const double2 r0 = *reinterpret_cast<const double2 *>(rating + i0[k]);
+      const double2 r1 = *reinterpret_cast<const double2 *>(rating + i0[k] + 2);
+      R[k][0] = r0.x, R[k][1] = r0.y, R[k][2] = r1.x, R[k][3] = r1.y;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) R[k][j] = i0[k] + j < n ? rating[i0[k] + j] : 0.0;
     }
-    if (rating[i] >= thr[u]) atomicOr(&fav[(size_t)u * wwords + (a >> 5)], 1u << (a & 31));
   }
+#pragma unroll
+  for (int k = 0; k < kIt; ++k) {
+    const int32_t u[4] = {U[k].x, U[k].y, U[k].z, U[k].w}, a[4] = {A[k].x, A[k].y, A[k].z, A[k].w};
+    double t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = thr[(u[j] >= 0 && u[j] < n_users) ? u[j] : 0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (i0[k] + j >= n || u[j] < 0 || u[j] >= n_users) continue;
+      if (a[j] < 0 || a[j] >= n_anime) {
+        bad = true;
+        continue;
+      }
+      if (R[k][j] >= t[j]) atomicOr(&fav[(size_t)u[j] * wwords + (a[j] >> 5)], 1u << (a[j] & 31));
+    }
+  }
+  }
+  if (bad) *err = 1;
 }
 
 // One workgroup per query: counts[a] = number of similar users holding a as a favourite (a not a favourite
@@ -520,10 +659,12 @@ using namespace anirec;
 
 extern "C" {
 
-// cnt | ptr | cursor | csr_rating
+// cnt | ptr | cursor | csr_rating | 256 spare bytes | tile totals of the scan
+static inline size_t scan_tiles(int32_t n_users) { return ((size_t)n_users + kRsTile - 1) / kRsTile; }
 size_t anirec_fav_workspace_bytes(int64_t n_ratings, int32_t n_users) {
   if (n_ratings < 1 || n_users < 1) return 0;
-  return al256r((size_t)n_users * 4) + 2 * al256r(((size_t)n_users + 1) * 8) + al256r((size_t)n_ratings * 8) + 256;
+  return al256r((size_t)n_users * 4) + 2 * al256r(((size_t)n_users + 1) * 8) + al256r((size_t)n_ratings * 8) + 256 +
+         al256r(scan_tiles(n_users) * 8);
 }
 
 int anirec_user_favourites(const int32_t *user_idx, const int32_t *anime_idx, const double *rating, int64_t n,
@@ -533,6 +674,8 @@ int anirec_user_favourites(const int32_t *user_idx, const int32_t *anime_idx, co
   if (!user_idx || !anime_idx || !rating || !fav_bits || !threshold || !err_flag || !workspace) return ANIREC_EINVAL;
   if (n < 1 || n_users < 1 || n_anime < 1 || !(percentile >= 0.0 && percentile <= 100.0)) return ANIREC_EINVAL;
   if (workspace_bytes < anirec_fav_workspace_bytes(n, n_users)) return ANIREC_EWORKSPACE;
+  if (((uintptr_t)user_idx | (uintptr_t)anime_idx | (uintptr_t)rating | (uintptr_t)workspace) & 15)
+    return ANIREC_EINVAL;  // the columns are read 16 bytes at a time
   hipStream_t s = (hipStream_t)stream;
   char *p = (char *)workspace;
   int32_t *cnt = (int32_t *)p;
@@ -543,19 +686,33 @@ int anirec_user_favourites(const int32_t *user_idx, const int32_t *anime_idx, co
   p += al256r(((size_t)n_users + 1) * 8);
   double *csr = (double *)p;
   const int wwords = (n_anime + 31) / 32;
-  int32_t *unsorted = (int32_t *)((char *)csr + al256r((size_t)n * 8));  // the spare 256 B at the end
+  int32_t *unsorted = (int32_t *)((char *)csr + al256r((size_t)n * 8));  // the spare 256 B
+  long long *tsum = (long long *)((char *)unsorted + 256);
+  const int n_tiles = (int)scan_tiles(n_users);
+  const unsigned gq = (unsigned)((n + 1024 * kRecIters - 1) / (1024 * kRecIters));
   ANIREC_HIP_CHECK(hipMemsetAsync(err_flag, 0, 4, s));
   ANIREC_HIP_CHECK(hipMemsetAsync(unsorted, 0, 4, s));
   ANIREC_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)n_users * 4, s));
-  ANIREC_HIP_CHECK(hipMemsetAsync(fav_bits, 0, (size_t)n_users * wwords * 4, s));
   const int g = grid_rec(n);
-  hipLaunchKernelGGL(k_rec_count, dim3(g), dim3(256), 0, s, user_idx, n, n_users, cnt, err_flag, unsorted);
-  hipLaunchKernelGGL(k_rec_scan, dim3(1), dim3(1024), 0, s, cnt, n_users, ptr, cursor);
+  // the bit rows are built inside k_rec_percentile when the table is grouped by user and a row fits the LDS budget
+  const int fused = (size_t)wwords * 16 <= 48 * 1024 ? 1 : 0;
+  const size_t fav_words = (size_t)n_users * wwords;
+  hipLaunchKernelGGL(k_rec_count, dim3(gq), dim3(256), 0, s, user_idx, n, n_users, cnt, err_flag, unsorted);
+  hipLaunchKernelGGL(k_rec_scan_reduce, dim3(n_tiles), dim3(256), 0, s, cnt, n_users, tsum);
+  hipLaunchKernelGGL(k_rec_scan_spine, dim3(1), dim3(1024), 0, s, tsum, n_tiles, ptr, n_users);
+  hipLaunchKernelGGL(k_rec_scan_apply, dim3(n_tiles), dim3(256), 0, s, cnt, n_users, tsum, ptr, cursor);
+  if ((fav_words & 3) == 0 && (((uintptr_t)fav_bits) & 15) == 0) {
+    hipLaunchKernelGGL(k_rec_clear, dim3(4096), dim3(256), 0, s, (uint4 *)fav_bits, fav_words / 4, unsorted, fused);
+  } else {
+    ANIREC_HIP_CHECK(hipMemsetAsync(fav_bits, 0, fav_words * 4, s));
+  }
   hipLaunchKernelGGL(k_rec_scatter, dim3(g), dim3(256), 0, s, user_idx, rating, n, n_users, cursor, unsorted, csr);
-  hipLaunchKernelGGL(k_rec_percentile, dim3((n_users + 3) / 4), dim3(256), 0, s, csr, ptr, n_users, percentile,
-                     threshold);
-  hipLaunchKernelGGL(k_rec_favbits, dim3(g), dim3(256), 0, s, user_idx, anime_idx, rating, n, n_users, n_anime,
-                     threshold, fav_bits, wwords, err_flag);
+  const FavFuse ff{rating, anime_idx, unsorted, fused ? fav_bits : nullptr, wwords, n_anime, err_flag};
+  hipLaunchKernelGGL(k_rec_percentile, dim3((n_users + 3) / 4), dim3(256), fused ? (size_t)wwords * 16 : 0, s, csr, ptr,
+                     n_users, percentile, threshold, ff);
+  const int64_t fb = (n + 2047) / 2048;
+  hipLaunchKernelGGL(k_rec_favbits, dim3((unsigned)(fb < 8192 ? fb : 8192)), dim3(256), 0, s, user_idx, anime_idx, rating, n,
+                     n_users, n_anime, threshold, fav_bits, wwords, err_flag, unsorted, fused);
   return (int)hipGetLastError();
 }
 

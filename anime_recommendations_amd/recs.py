@@ -18,6 +18,12 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _aligned(t):
+    """Contiguous and 16-byte aligned (the kernels read four rows per lane): a sliced view is copied."""
+    t = t.contiguous()
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
 def user_favourites(user_idx, anime_idx, rating, n_users, n_anime, percentile=80.0):
     """Returns (fav_bits int32 [n_users, ceil(n_anime/32)], threshold float64 [n_users]).
     Bit a of row u is set iff rating(u, a) >= np.percentile(ratings of u, percentile)."""
@@ -25,9 +31,9 @@ def user_favourites(user_idx, anime_idx, rating, n_users, n_anime, percentile=80
         raise _lib.AnirecError("no GPU: the anime_recommendations_amd recs path needs an MI355X")
     lib = _lib.load()
     dev = user_idx.device
-    u = user_idx.to(torch.int32).contiguous()
-    a = anime_idx.to(torch.int32).contiguous()
-    r = rating.to(torch.float64).contiguous()
+    u = _aligned(user_idx.to(torch.int32))
+    a = _aligned(anime_idx.to(torch.int32))
+    r = _aligned(rating.to(torch.float64))
     n = int(u.numel())
     ww = (int(n_anime) + 31) // 32
     fav = torch.empty(int(n_users), ww, dtype=torch.int32, device=dev)

@@ -532,14 +532,17 @@ def run_user_recs(cpu_baseline=True):
     torch.cuda.synchronize()
     dt_r = (time.perf_counter() - t0) / reps
     ww = (n_anime + 31) // 32
-    fav_bytes = 16 * n + 16 * n + (n_users * ww * 4)      # count + CSR pass, percentile + bit pass, bit rows written
+    fav_bytes = 16 * n + (n_users * ww * 4)               # the three columns read once, the bit rows written once
     rec_bytes = nq * (k_sim + 1) * ww * 4                 # the similar users' and the query's bit rows
     rec = {"value": nq / dt_r, "unit": "queries/s", "ms": dt_r * 1e3,
            "favourites": {"ms": dt_f * 1e3, "ratings_per_s": n / dt_f,
-                          "roofline": {"kernel": "k_rec_count/scatter/percentile/favbits (5 launches)", "bound": "hbm",
+                          "roofline": {"kernel": "k_rec_count, 3-launch scan, k_rec_percentile with the favourite-bit rows "
+                                                 "built in LDS (table grouped by user); 8 launches", "bound": "hbm",
                                        "achieved": fav_bytes / dt_f / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": fav_bytes / dt_f / 1e9 / HBM_PEAK_GBS,
-                                       "traffic": pmc_traffic("recs", {"k_rec_count": 1, "k_rec_scan": 1, "k_rec_scatter": 1,
+                                       "traffic": pmc_traffic("recs", {"k_rec_count": 1, "k_rec_scan_reduce": 1,
+                                                                       "k_rec_scan_spine": 1, "k_rec_scan_apply": 1,
+                                                                       "k_rec_clear": 1, "k_rec_scatter": 1,
                                                                        "k_rec_percentile": 1, "k_rec_favbits": 1},
                                                               source="anirec_recs.hip")}},
            "roofline": {"kernel": "k_user_recs<3, 4> (one workgroup per query: 11 bit rows of 2.25 KB -> bit-sliced counts in registers, block-wide binary searches for the cut -> top-10)",
