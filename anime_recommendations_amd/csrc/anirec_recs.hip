@@ -238,11 +238,30 @@ __global__ __launch_bounds__(256) void k_rec_percentile(const double *csr_rating
     const int shift = 56 - 8 * pass;
     for (int b = lane; b < 256; b += 64) h[b] = 0;
     __builtin_amdgcn_wave_barrier();
+    unsigned long long orv = 0ull, andv = ~0ull;  // OR / AND of the keys still in play, per lane
+    bool mine = false;
     for (long long i = lane; i < n; i += 64) {
       const unsigned long long k = dkey(csr_rating[s0 + i]);
-      if ((k & pmask) == prefix) atomicAdd(&h[(k >> shift) & 255ull], 1u);
+      if ((k & pmask) == prefix) {
+        atomicAdd(&h[(k >> shift) & 255ull], 1u);
+        orv |= k;
+        andv &= k;
+        mine = true;
+      }
     }
     __builtin_amdgcn_wave_barrier();
+    // Every key still in play equal (ratings on a grid of 11 values: true after two passes)?  Then it is x_(lo)
+    // and the remaining passes would only confirm its bytes one by one.
+    {
+      const unsigned long long has = __ballot(mine);
+      const int first = __ffsll((long long)has) - 1;  // has != 0: want < the number of keys in play
+      const unsigned long long k0 = (unsigned long long)__shfl((long long)orv, first, 64);
+      const bool differs = mine && (orv != andv || orv != k0);
+      if (__ballot(differs) == 0ull) {
+        prefix = k0;
+        break;
+      }
+    }
     // ascending digit walk by a wave scan: lane l covers digits 4l .. 4l+3
     uint32_t h4[4], run = 0;
 #pragma unroll
