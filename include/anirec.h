@@ -320,7 +320,9 @@ typedef struct anirec_ingest_opts {
 
 /* rating: float64, NaN = missing.  Outputs hold up to n rows; *n_out (device) receives the row
  * count; *err_flag (device) becomes 1 if a non-missing id is outside its bound (that row is
- * dropped).  1 <= n < 2^30. */
+ * dropped).  1 <= n < 2^30.  The five input columns and the workspace must be 16-byte aligned
+ * (ANIREC_EINVAL otherwise: the kernels read four rows per lane).  Any row order is accepted; a table
+ * grouped by user (the raw animelist) finds its duplicate rows in LDS, chunk by chunk. */
 size_t anirec_ingest_workspace_bytes(int64_t n, int32_t user_id_bound, int32_t anime_id_bound);
 int anirec_ingest_preprocess(const int32_t *user_id, const int32_t *anime_id, const double *rating,
                              const int32_t *watching_status, const int32_t *watched_episodes, int64_t n,
@@ -337,7 +339,8 @@ int anirec_ingest_half_columns(const int32_t *out_anime_id, const int64_t *n_out
                                const void *workspace, size_t workspace_bytes, void *stream);
 
 /* out_index[i] = position of id[i] in the order of first appearance (pandas Series.unique());
- * out_uniques[j] = the j-th distinct id; *n_unique (device) = number of distinct ids. */
+ * out_uniques[j] = the j-th distinct id; *n_unique (device) = number of distinct ids.
+ * id, out_index and the workspace must be 16-byte aligned. */
 size_t anirec_ingest_encode_workspace_bytes(int64_t n, int32_t id_bound);
 int anirec_ingest_encode(const int32_t *id, int64_t n, int32_t id_bound, int32_t *out_index,
                          int32_t *out_uniques, int64_t *n_unique, int32_t *err_flag, void *workspace,
@@ -353,7 +356,10 @@ int anirec_ingest_encode(const int32_t *id, int64_t n, int32_t id_bound, int32_t
 
 /* fav_bits[n_users][ceil(n_anime/32)]: bit a of row u set iff rating(u, a) >= threshold[u];
  * threshold[u] = np.percentile(ratings of u, percentile) bit for bit (NaN for users without ratings).
- * Ratings must not contain NaN.  *err_flag (device) becomes 1 on an out-of-range index. */
+ * Ratings must not contain NaN.  *err_flag (device) becomes 1 on an out-of-range index.
+ * The three columns and the workspace must be 16-byte aligned (ANIREC_EINVAL otherwise).  A table grouped by user
+ * (non-decreasing user_idx: the raw / preprocessed order) is detected on the device and takes the fast path: no CSR
+ * copy, the bit rows built per user and written once. */
 size_t anirec_fav_workspace_bytes(int64_t n_ratings, int32_t n_users);
 int anirec_user_favourites(const int32_t *user_idx, const int32_t *anime_idx, const double *rating, int64_t n,
                            int32_t n_users, int32_t n_anime, double percentile, uint32_t *fav_bits,
