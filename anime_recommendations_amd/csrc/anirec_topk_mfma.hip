@@ -66,6 +66,11 @@ namespace anirec {
 // query rows per workgroup: 32 per wave x kWaves (4 or 8) waves, template parameter of k_cand
 constexpr int kBN = 128;        // keys per tile
 constexpr int kCap = 512;       // candidate buffer entries per query row
+// Key-range SPLITS (small query sets: fewer workgroups than CUs): gridDim.y workgroups share a row block and a
+// super-step's key tiles; split s appends into its own region of the row's buffer, [kKept + s kReg, + kReg),
+// with its own count (cnt2), and k_refresh folds the regions behind the kept entries [0, cnt).
+constexpr int kKept = 128, kReg = 96, kMaxSplit = (kCap - kKept) / kReg;  // 128 + 4 x 96 = 512
+static_assert(kMaxSplit == 4, "cnt2 rows are read as one int4");
 // |fp16-operand MFMA score - fp32 fma-chain score| for unit-norm rows: each operand is rounded with
 // unit roundoff 2^-11 (fp16 has 11 significant bits: 8x tighter than bf16's 2^-8, at the same MFMA
 // rate), so a product is off by <= 2^-10 (1 + 2^-12) of |q_k w_k| and sum |q_k w_k| <= 1; fp16
@@ -159,6 +164,8 @@ struct CandArgs {
   int tile0, tile1;  // this launch scans key tiles [tile0, tile1)
   uint2 *cand;       // [nq][kCap] {score bits, key index}
   int32_t *cnt;      // [nq]
+  int32_t *cnt2;     // [nq][kMaxSplit] entries in the split regions (zero outside a split super-step)
+  int splits;        // gridDim.y of this launch
   float *theta;      // [nq]
   int32_t *flags;    // [nq] bit0: buffer overflow (dense ties)
   unsigned long long *dbg;  // kDbg == 2: [0] total appends
@@ -213,7 +220,37 @@ __global__ __launch_bounds__(64) void k_refresh(CandArgs a) {
   const int lane = threadIdx.x;
   const int row = blockIdx.x;
   uint2 *cand_row = a.cand + (size_t)row * kCap;
-  const int c = min(a.cnt[row], kCap);
+  int c = min(a.cnt[row], kCap);
+  {  // fold what a split super-step left in the regions behind the kept entries (all regions are read before
+     // the first write: the destination may run into them)
+    const int4 c2 = *reinterpret_cast<const int4 *>(a.cnt2 + (size_t)row * kMaxSplit);
+    if (c2.x | c2.y | c2.z | c2.w) {
+      const int cs[kMaxSplit] = {c2.x, c2.y, c2.z, c2.w};
+      constexpr int kRs = (kReg + 63) / 64;  // register slots per region
+      uint2 r[kMaxSplit][kRs];
+#pragma unroll
+      for (int sp = 0; sp < kMaxSplit; ++sp)
+#pragma unroll
+        for (int j = 0; j < kRs; ++j) {
+          const int e = lane + 64 * j;
+          r[sp][j] = e < cs[sp] ? cand_row[kKept + sp * kReg + e] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+      for (int sp = 0; sp < kMaxSplit; ++sp) {
+#pragma unroll
+        for (int j = 0; j < kRs; ++j) {
+          const int e = lane + 64 * j;
+          if (e < cs[sp] && c + e < kCap) cand_row[c + e] = r[sp][j];
+        }
+        c += cs[sp];
+      }
+      c = min(c, kCap);
+      if (lane == 0) {
+        *reinterpret_cast<int4 *>(a.cnt2 + (size_t)row * kMaxSplit) = make_int4(0, 0, 0, 0);
+        a.cnt[row] = c;
+      }
+    }
+  }
   if (c < a.k_eff) return;  // not enough candidates yet (tiny tables): keep the threshold
   if (c <= 64)
     refresh_row<1>(a, cand_row, row, c, lane);
@@ -283,9 +320,18 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
                    : "v"(doff[i]), "s"(base), "s"(l0 + 1024u * i)
                    : "memory", "m0");
   };
-  const int nt = a.tile1 - a.tile0;
-  dma_tile(a.tile0, 0);
-  if (nt > 1) dma_tile(a.tile0 + 1, 1);
+  // this workgroup's share of the super-step's key tiles
+  const int split = blockIdx.y;
+  int tile_lo = a.tile0, tile_hi = a.tile1;
+  if (a.splits > 1) {
+    const int len = (a.tile1 - a.tile0 + a.splits - 1) / a.splits;
+    tile_lo = a.tile0 + split * len;
+    tile_hi = min(a.tile1, tile_lo + len);
+    if (tile_hi <= tile_lo) return;  // the whole workgroup: nothing left for this split
+  }
+  const int nt = tile_hi - tile_lo;
+  dma_tile(tile_lo, 0);
+  if (nt > 1) dma_tile(tile_lo + 1, 1);
   // kMask: the four 32-key mask words of each of the wave's 32 query rows travel global -> LDS by LDS-DMA as
   // well (two 256-B pieces per tile and wave into a wave-private [3][32][4] image, two tiles ahead), so they
   // are covered by the same hand-placed vmcnt waits as the key tiles.  (Plain loads into registers made the
@@ -316,8 +362,8 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
     }
   };
   if (kMask) {
-    dma_mask(a.tile0, 0);
-    if (nt > 1) dma_mask(a.tile0 + 1, 1);
+    dma_mask(tile_lo, 0);
+    if (nt > 1) dma_mask(tile_lo + 1, 1);
   }
 
   // Accumulator register i of block (rb, nb) belongs to query row 16 rb + 4 gq + i of the wave's 32
@@ -333,8 +379,10 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
       const int rl = q0 + 32 * w + 16 * rb + 4 * gq + i;
       const bool live = rl < a.nq;
       nthr[rb][i] = live ? -a.theta[rl] : -INFINITY;
-      cntr[rb][i] = live ? a.cnt[rl] : 0;
-      rowoff[rb][i] = (uint32_t)rl * (uint32_t)(kCap * 8);
+      // a split appends to its own (empty) region; the kept entries must then end before the regions begin
+      cntr[rb][i] = (live && a.splits == 1) ? a.cnt[rl] : 0;
+      if (live && a.splits > 1 && split == 0 && c16 == 0 && a.cnt[rl] > kKept) a.flags[rl] |= 1;
+      rowoff[rb][i] = (uint32_t)rl * (uint32_t)(kCap * 8) + (a.splits > 1 ? (uint32_t)((kKept + split * kReg) * 8) : 0u);
     }
   // LDS read addresses of the B fragments: key row 32 cb + 16 nb + c16 has (row & 15) == c16, so the
   // swizzled chunk index depends only on (kk, lane); buffer, cb and nb are constant offsets
@@ -342,6 +390,7 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk)
     kb[kk] = reinterpret_cast<const f16x8 *>(&Ks[0][c16 * 16 + ((4 * kk + gq) ^ c16)]);
+  const uint32_t cap = a.splits > 1 ? (uint32_t)kReg : (uint32_t)kCap;  // entries this workgroup may append per row
   const uint32_t lt16 = (1u << c16) - 1u;
   const int sh16 = 16 * gq;
   char *const cand_bytes = reinterpret_cast<char *>(a.cand);
@@ -417,7 +466,7 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
           if (mk) {  // wave-uniform
             const uint32_t mh = (uint32_t)(mk >> sh16) & 0xFFFFu;  // the quarter-wave (= row) of this lane
             const uint32_t pos = (uint32_t)cntr[rb][i] + __popc(mh & lt16);
-            if (hit && pos < (uint32_t)kCap)
+            if (hit && pos < cap)
               *reinterpret_cast<uint2 *>(cand_bytes + (rowoff[rb][i] + pos * 8u)) =
                   make_uint2(__float_as_uint(cv[i] - nthr[rb][i]), (uint32_t)key);
             cntr[rb][i] += __popc(mh);
@@ -441,7 +490,7 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
   if (kDbg == 4) dbg_t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < nt; ++it) {
     const int buf = it & 1;
-    const int key0 = (a.tile0 + it) * kBN;
+    const int key0 = (tile_lo + it) * kBN;
     const int ms = (it % 3) * 128;                     // this tile's slot in the wave's LDS mask image
     stage_fn(acc0, acc1, key0, buf, 2, ms + 0);        // filter block 0 | MFMA block 1 | fetch block 2
     stage_fn(acc1, acc0, key0 + 32, buf, 3, ms + 1);   // filter block 1 | MFMA block 2 | fetch block 3
@@ -462,8 +511,8 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
     }
     // this tile's buffer was last read (fetched) before the barrier: refill it with tile it+2, in
     // flight for a whole tile
-    if (kMask && it + 2 < nt) dma_mask(a.tile0 + it + 2, (it + 2) % 3);  // its slot was tile it-1's
-    if (it + 2 < nt) dma_tile(a.tile0 + it + 2, buf);
+    if (kMask && it + 2 < nt) dma_mask(tile_lo + it + 2, (it + 2) % 3);  // its slot was tile it-1's
+    if (it + 2 < nt) dma_tile(tile_lo + it + 2, buf);
     // on the last tile the "next tile" blocks are stale LDS: computed and thrown away
     stage_fn(acc0, acc1, key0 + 64, buf ^ 1, 0, ms + 2);  // filter block 2 | MFMA block 3 | fetch next tile's block 0
     stage_fn(acc1, acc0, key0 + 96, buf ^ 1, 1, ms + 3);  // filter block 3 | MFMA next block 0 | fetch next block 1
@@ -482,8 +531,11 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
       for (int i = 0; i < 4; ++i) {
         const int rl = q0 + 32 * w + 16 * rb + 4 * gq + i;
         if (rl < a.nq) {
-          a.cnt[rl] = min(cntr[rb][i], kCap);
-          if (cntr[rb][i] > kCap) a.flags[rl] |= 1;  // the super-step produced more candidates than the buffer holds
+          if (a.splits > 1)
+            a.cnt2[(size_t)rl * kMaxSplit + split] = min(cntr[rb][i], (int)cap);
+          else
+            a.cnt[rl] = min(cntr[rb][i], kCap);
+          if (cntr[rb][i] > (int)cap) a.flags[rl] |= 1;  // more candidates than the buffer / the region holds
         }
       }
   }
@@ -714,17 +766,31 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
   int first = (4 * ca.k_eff + kBN - 1) / kBN;
   if (first > (kCap - kBN) / kBN) first = (kCap - kBN) / kBN;
   if (first < 1) first = 1;
+  // Few queries: fewer workgroups than the chip holds.  From the second super-step on the key tiles of a super-
+  // step are then split over up to kMaxSplit workgroups per row block (the first one, with no threshold yet,
+  // needs the whole buffer of a row).
+  const char *spe = getenv("ANIREC_TOPK_SPLITS");
+  const int wg_slots = 256 * (wide ? 1 : 2);
+  int max_split = spe ? atoi(spe) : wg_slots / (int)grid.x;
+  if (max_split > kMaxSplit) max_split = kMaxSplit;
+  if (max_split < 1 || ca.k_eff + 16 > kKept) max_split = 1;  // the kept entries (k_eff + the 2 eps window) must fit
+  bool regions_used = false;
   for (int t0 = 0, step = first; t0 < ntiles;) {
     const int t1 = t0 + step < ntiles ? t0 + step : ntiles;
     ca.tile0 = t0;
     ca.tile1 = t1;
+    int splits = t0 == 0 ? 1 : max_split;
+    while (splits > 1 && (t1 - t0) < 2 * splits) --splits;  // at least two tiles per workgroup
+    ca.splits = splits;
+    const dim3 grid2(grid.x, splits);
+    regions_used = splits > 1;
 #define ANIREC_LAUNCH_CAND(D, M)                                                                    \
   do {                                                                                              \
     const size_t shm = (M) ? (size_t)(wide ? 8 : 4) * 3 * 512 : 0;  /* the waves' LDS mask images */   \
     if (wide)                                                                                       \
-      hipLaunchKernelGGL((k_cand<D, 8, M>), grid, block, shm, s, ca);                               \
+      hipLaunchKernelGGL((k_cand<D, 8, M>), grid2, block, shm, s, ca);                              \
     else                                                                                            \
-      hipLaunchKernelGGL((k_cand<D, 4, M>), grid, block, shm, s, ca);                               \
+      hipLaunchKernelGGL((k_cand<D, 4, M>), grid2, block, shm, s, ca);                              \
   } while (0)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (g_time_cand) {
@@ -748,7 +814,8 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
       timed.push_back(ev0);
       timed.push_back(ev1);
     }
-    if (t1 < ntiles) hipLaunchKernelGGL(k_refresh, dim3(nq), dim3(64), 0, s, ca);
+    // (after the last super-step only to fold the split regions: the re-rank reads one list per row)
+    if (t1 < ntiles || regions_used) hipLaunchKernelGGL(k_refresh, dim3(nq), dim3(64), 0, s, ca);
     ANIREC_HIP_CHECK(hipGetLastError());
     step = (int)((long long)t1 * growth_pct / 100);  // next super-step: growth_pct % of the tiles seen so far
     if (step < 1) step = 1;
@@ -778,6 +845,7 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
       }
       ca.tile0 = 0;
       ca.tile1 = ntiles;
+      ca.splits = 1;
       hipEvent_t e0, e1;
       (void)hipEventCreate(&e0);
       (void)hipEventCreate(&e1);
@@ -834,11 +902,12 @@ int anirec_topk_mfma_timing(int32_t enable, float *cand_ms, int32_t *launches) {
 // Wb holds whole key tiles: rows n .. padded_keys(n)-1 are NaN rows (never candidates)
 static inline size_t padded_keys(int32_t n) { return ((size_t)n + kBN - 1) / kBN * kBN; }
 
-// workspace: Wb (padded_keys(n)*256 B) | Qb (nq*256 B) | cand (nq*kCap*8) | cnt, theta (nq*4 each)
+// workspace: Wb (padded_keys(n)*256 B) | Qb (nq*256 B) | cand (nq*kCap*8) | cnt, theta (nq*4 each) | 256 B | cnt2
 size_t anirec_topk_mfma_workspace_bytes(int32_t n, int32_t nq) {
   if (n < 1 || nq < 1) return 0;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-  return al(padded_keys(n) * 256) + al((size_t)nq * 256) + al((size_t)nq * kCap * 8) + 2 * al((size_t)nq * 4) + 256;
+  return al(padded_keys(n) * 256) + al((size_t)nq * 256) + al((size_t)nq * kCap * 8) + 2 * al((size_t)nq * 4) + 256 +
+         al((size_t)nq * kMaxSplit * 4);
 }
 
 int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries, int32_t nq,
@@ -866,7 +935,9 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
   int b1 = (n + 7) / 8, b2 = (nq + 7) / 8;
   if (b1 > 8192) b1 = 8192;
   if (b2 > 8192) b2 = 8192;
-  int32_t *unnorm = (int32_t *)(p + 64);  // inside the 256 spare bytes at the end of the workspace
+  int32_t *unnorm = (int32_t *)(p + 64);  // inside the 256 spare bytes
+  int32_t *cnt2 = (int32_t *)(p + 256);
+  ANIREC_HIP_CHECK(hipMemsetAsync(cnt2, 0, (size_t)nq * kMaxSplit * 4, s));
   hipLaunchKernelGGL(k_init_rows, dim3((nq + 255) / 256), dim3(256), 0, s, cnt, theta, flags_out, nq, unnorm);
   hipLaunchKernelGGL(k_to_f16, dim3(b1), dim3(256), 0, s, What, nullptr, n, (int)padded_keys(n), keep, 0, Wb, unnorm);
   hipLaunchKernelGGL(k_to_f16, dim3(b2), dim3(256), 0, s, What, queries, nq, nq, nullptr, 1, Qb, unnorm);
@@ -879,6 +950,8 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
   ca.k_eff = exclude_self ? k + 1 : k;
   ca.cand = cand;
   ca.cnt = cnt;
+  ca.cnt2 = cnt2;
+  ca.splits = 1;
   ca.theta = theta;
   ca.flags = flags_out;
   ca.dbg = nullptr;
@@ -926,12 +999,13 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
 // ------------------------------------------------------------------------------------------------
 // model_recs batched: top-k unwatched anime by predicted rating for many users, on the matrix cores.
 // ------------------------------------------------------------------------------------------------
-// Ah (n_anime fp32 rows) | Uh (n_users fp32 rows) | Wb | Qb | cand | cnt | theta
+// Ah (n_anime fp32 rows) | Uh (n_users fp32 rows) | Wb | Qb | cand | cnt | theta | 256 B | cnt2
 size_t anirec_predict_topk_mfma_workspace_bytes(int32_t n_anime, int32_t n_users) {
   if (n_anime < 1 || n_users < 1) return 0;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   return al((size_t)n_anime * 512) + al((size_t)n_users * 512) + al(padded_keys(n_anime) * 256) +
-         al((size_t)n_users * 256) + al((size_t)n_users * kCap * 8) + 2 * al((size_t)n_users * 4) + 256;
+         al((size_t)n_users * 256) + al((size_t)n_users * kCap * 8) + 2 * al((size_t)n_users * 4) + 256 +
+         al((size_t)n_users * kMaxSplit * 4);
 }
 
 int anirec_predict_topk_mfma(const float *U, const float *A, int32_t n_anime, const int32_t *users,
@@ -960,6 +1034,9 @@ int anirec_predict_topk_mfma(const float *U, const float *A, int32_t n_anime, co
   int32_t *cnt = (int32_t *)p;
   p += al((size_t)n_users * 4);
   float *theta = (float *)p;
+  p += al((size_t)n_users * 4);
+  int32_t *cnt2 = (int32_t *)(p + 256);
+  ANIREC_HIP_CHECK(hipMemsetAsync(cnt2, 0, (size_t)n_users * kMaxSplit * 4, s));
   // sigmoid(gamma*(w*c+b-mu)/sqrt(var+eps)+beta) = sigmoid(c*hs + hb), folded exactly as the exact path does
   float hs, hb;
   head_affine_f32(head, &hs, &hb);
@@ -979,6 +1056,8 @@ int anirec_predict_topk_mfma(const float *U, const float *A, int32_t n_anime, co
   ca.k_eff = k;
   ca.cand = cand;
   ca.cnt = cnt;
+  ca.cnt2 = cnt2;
+  ca.splits = 1;
   ca.theta = theta;
   ca.flags = flags_out;
   ca.dbg = nullptr;
