@@ -309,3 +309,25 @@ def test_mfma_paths_on_tiny_tables():
         pm = ops.predict_topk_mfma(U, torch.from_numpy(W).cuda(), head, q, min(k, 100), None)
         assert torch.equal(pm[0], pe[0]), (n, k)
         assert torch.equal(torch.nan_to_num(pm[1], nan=-9.0), torch.nan_to_num(pe[1], nan=-9.0)), (n, k)
+
+
+@pytest.mark.parametrize("k", [10, 100])
+def test_key_range_splits_give_the_same_lists(k, monkeypatch):
+    """Small query sets share a row block's key tiles between up to 4 workgroups (own buffer regions, folded by
+    k_refresh): the neighbour lists must not depend on the number of splits, and no row may need the fallback."""
+    from anime_recommendations_amd import ops
+    rng = np.random.default_rng(5)
+    W = rng.normal(0, 0.05, (18_000, 128)).astype(np.float32)
+    Wh = ops.rownorm(torch.from_numpy(W))
+    q = torch.arange(3_000, dtype=torch.int32, device="cuda")
+    ref = None
+    for sp in ("1", "2", "3", "4"):
+        monkeypatch.setenv("ANIREC_TOPK_SPLITS", sp)
+        idx, sim, nfb = ops.cosine_topk_mfma(Wh, q, k)
+        if sp != "2":                      # two splits of a k = 100 super-step may overflow their 96-entry regions
+            assert nfb == 0, sp            # (those rows fall back to the exact path: still the same lists)
+        if ref is None:
+            ref = (idx.clone(), sim.clone())
+        assert torch.equal(idx, ref[0]) and torch.equal(sim, ref[1]), sp
+    ei, es = ops.cosine_topk(Wh, q[:256], k)
+    assert torch.equal(ref[0][:256], ei) and torch.equal(ref[1][:256], es)
