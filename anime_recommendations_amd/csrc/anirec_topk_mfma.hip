@@ -69,7 +69,7 @@ constexpr int kCap = 512;       // candidate buffer entries per query row
 // Key-range SPLITS (small query sets: fewer workgroups than CUs): gridDim.y workgroups share a row block and a
 // super-step's key tiles; split s appends into its own region of the row's buffer, [kKept + s kReg, + kReg),
 // with its own count (cnt2), and k_refresh folds the regions behind the kept entries [0, cnt).
-constexpr int kKept = 128, kReg = 96, kMaxSplit = (kCap - kKept) / kReg;  // 128 + 4 x 96 = 512
+constexpr int kKept = 160, kReg = 88, kMaxSplit = (kCap - kKept) / kReg;  // 160 + 4 x 88 = 512
 static_assert(kMaxSplit == 4, "cnt2 rows are read as one int4");
 // |fp16-operand MFMA score - fp32 fma-chain score| for unit-norm rows: each operand is rounded with
 // unit roundoff 2^-11 (fp16 has 11 significant bits: 8x tighter than bf16's 2^-8, at the same MFMA
@@ -769,9 +769,26 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
   // Few queries: fewer workgroups than the chip holds.  From the second super-step on the key tiles of a super-
   // step are then split over up to kMaxSplit workgroups per row block (the first one, with no threshold yet,
   // needs the whole buffer of a row).
+  // The same splits smooth the wave quantisation of bigger launches: 391 workgroups on 256 CUs run as two full
+  // rounds; cut in three they run as five rounds of a third of the length (1.67).
   const char *spe = getenv("ANIREC_TOPK_SPLITS");
   const int wg_slots = 256 * (wide ? 1 : 2);
-  int max_split = spe ? atoi(spe) : wg_slots / (int)grid.x;
+  // A row gains about k_eff * growth candidates per super-step, spread over the splits: a region (kReg entries)
+  // must hold its share with a wide margin, so few splits are not an option for large k.
+  const int min_split = (int)((2.5 * ca.k_eff * growth_pct / 100.0 + kReg - 1) / kReg);
+  int max_split = 1;
+  if (spe) {
+    max_split = atoi(spe);
+  } else {
+    double best = (double)(((long long)grid.x + wg_slots - 1) / wg_slots);  // rounds without splits
+    for (int sp = min_split > 2 ? min_split : 2; sp <= kMaxSplit; ++sp) {
+      const double rounds = (double)(((long long)grid.x * sp + wg_slots - 1) / wg_slots) / sp;
+      if (rounds < best * 0.97) {  // a larger split must buy at least 3 %
+        best = rounds;
+        max_split = sp;
+      }
+    }
+  }
   if (max_split > kMaxSplit) max_split = kMaxSplit;
   if (max_split < 1 || ca.k_eff + 16 > kKept) max_split = 1;  // the kept entries (k_eff + the 2 eps window) must fit
   bool regions_used = false;
@@ -781,6 +798,7 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
     ca.tile1 = t1;
     int splits = t0 == 0 ? 1 : max_split;
     while (splits > 1 && (t1 - t0) < 2 * splits) --splits;  // at least two tiles per workgroup
+    if (splits > 1 && splits < min_split) splits = 1;
     ca.splits = splits;
     const dim3 grid2(grid.x, splits);
     regions_used = splits > 1;
