@@ -476,7 +476,7 @@ def run_predict_topk(cpu_baseline=True):
     rec = {"value": nq / dt, "unit": "users/s", "ms": dt * 1e3, "k": k, "fallback_rows": int(nfb),
            "ratings_per_s": nq * n_a / dt, "exact_fp32_path_ms": dte * 1e3,
            "roofline": {"kernel": "k_cand<masked> (f16 MFMA cosine + watched mask + candidate filter), %d launches; "
-                                  "18 k keys = 141 tiles only: ~60 appends per tile-wave, launch-bound" % cand_launches,
+                                  "18 k keys = 141 tiles only: ~60 appends per tile-wave, append-bound" % cand_launches,
                         "bound": "mfma", "achieved": tfk, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": tfk / MFMA_F16_PEAK_TFLOPS, "kernel_ms": cand_ms,
                         # scripts/time_predict_topk.py calls the op twice: all k_cand launches of ONE call
