@@ -152,3 +152,30 @@ def test_user_recs_wide_tables(n_anime):
         m = len(want_a)
         assert out_a[j, :m].tolist() == want_a and out_c[j, :m].tolist() == want_c, j
         assert (out_a[j, m:] == -1).all() and (out_c[j, m:] == 0).all()
+
+
+@pytest.mark.parametrize("k_sim,n_recs", [(1, 1), (1, 7), (2, 256), (15, 5), (16, 5), (31, 64), (40, 3), (63, 256)])
+def test_user_recs_k_sim_and_n_recs_sweep(k_sim, n_recs):
+    """The selection is a pair of block-wide binary searches over bit-sliced counters (4 planes up to k_sim = 15,
+    6 above): every plane count, the search end points (k_sim = 1, cut at the top / at zero, n_recs larger than the
+    number of candidates) and heavy ties, against the pandas restatement."""
+    from anime_recommendations_amd import recs
+    rng = np.random.default_rng(1000 * k_sim + n_recs)
+    n_users, n_anime = 90, 1200
+    u = np.repeat(np.arange(n_users), 80).astype(np.int32)
+    a = np.concatenate([rng.choice(300 if uu % 3 else n_anime, 80, replace=False) for uu in range(n_users)]).astype(np.int32)
+    r = rng.integers(5, 11, len(u)) / 10
+    _, fav_o = orc.favourites(u, a, r.astype(np.float64), n_users)
+    fav, _ = recs.user_favourites(torch.as_tensor(u).cuda(), torch.as_tensor(a).cuda(), torch.as_tensor(r).double().cuda(),
+                                  n_users, n_anime)
+    queries = rng.integers(0, n_users, 40).astype(np.int32)
+    sims = np.stack([rng.choice(n_users, k_sim, replace=False) for _ in queries]).astype(np.int32)
+    if k_sim > 2:
+        sims[1, k_sim // 2:] = -1
+    out_a, out_c = recs.user_recs(fav, n_anime, queries, sims, n_recs)
+    out_a, out_c = out_a.cpu().numpy(), out_c.cpu().numpy()
+    for j, q in enumerate(queries):
+        want_a, want_c = orc.user_recs(fav_o, int(q), sims[j].tolist(), n_recs)
+        m = len(want_a)
+        assert out_a[j, :m].tolist() == want_a and out_c[j, :m].tolist() == want_c, (j, k_sim, n_recs)
+        assert (out_a[j, m:] == -1).all() and (out_c[j, m:] == 0).all()
