@@ -214,3 +214,16 @@ def test_unaligned_views_are_accepted_by_the_wrappers_and_rejected_by_the_c_entr
     rc = lib.anirec_ingest_encode(C.c_void_p(ids.data_ptr() + 4), n, 1000, _lib.ptr(out), _lib.ptr(out), _lib.ptr(z),
                                   _lib.ptr(z[2:]), _lib.ptr(ws), ws.numel(), None)
     assert rc == _lib.EINVAL if hasattr(_lib, "EINVAL") else rc < 0
+
+
+def test_preprocess_one_row_repeated_thousands_of_times():
+    """A chunk whose 8 192 rows are all the same row (every insert lands on one LDS slot), a run of them crossing
+    chunk boundaries, and the same again through the list path (the repeated user also appears at the far end)."""
+    base = _raw_frame(3_000, 40, 50, seed=4, nulls=False, dups=False, grouped=True)
+    row = base.iloc[[1234]]
+    rep = pd.concat([row] * 20_000, ignore_index=True)
+    for tail in (False, True):
+        parts = [base.iloc[:1234], rep, base.iloc[1234:]] + ([row] if tail else [])
+        df = pd.concat(parts, ignore_index=True)
+        want = _check(df, 10)
+        assert len(want) <= len(base)
