@@ -57,6 +57,7 @@ class FitResult:
     stopped_epoch: int = -1
     optimizer: dict = field(default_factory=dict)
     step_loop_seconds: list = field(default_factory=list)   # per epoch: wall time of the step loop alone (synchronised)
+    epoch_seconds: list = field(default_factory=list)       # per epoch: shuffle + steps + metrics + validation + snapshot
 
 
 def init_weights(n_users, n_anime, dim=128, seed=0):
@@ -117,8 +118,9 @@ def fit(table: RatingTable, cfg: FitConfig, engine=None, log=print, device="cuda
     best_w = None
     best_epoch, stopped, wait = -1, -1, 0
     t_global = 0
-    loop_s = []
+    loop_s, epoch_s = [], []
     for epoch in range(cfg.epochs):
+        t_epoch = time.perf_counter()
         lr = cfg.lr(epoch)
         gen.manual_seed(cfg.seed * 1_000_003 + epoch)
         perm = torch.randperm(n_train, generator=gen, device=dev)     # model.fit(shuffle=True)
@@ -157,13 +159,16 @@ def fit(table: RatingTable, cfg: FitConfig, engine=None, log=print, device="cuda
                 torch.cuda.synchronize(dev)   # the clones ran on torch's stream: finish before the next epoch writes W
         else:
             wait += 1
-            if wait >= cfg.patience and epoch > 0:                    # EarlyStopping
-                stopped = epoch
-                break
+        engine.synchronize()
+        epoch_s.append(time.perf_counter() - t_epoch)
+        if wait >= cfg.patience and epoch > 0:                        # EarlyStopping
+            stopped = epoch
+            break
     engine.synchronize()
     rec = engine.read_state()
     res = FitResult(history=hist, U=engine.U.cpu().numpy().copy(), A=engine.A.cpu().numpy().copy(),
-                    head=head_of(rec), best_epoch=best_epoch, stopped_epoch=stopped, step_loop_seconds=loop_s)
+                    head=head_of(rec), best_epoch=best_epoch, stopped_epoch=stopped, step_loop_seconds=loop_s,
+                    epoch_seconds=epoch_s)
     if hasattr(engine, "optimizer_state"):       # Adam m, v and the step count of the LAST epoch (model.save)
         res.optimizer = engine.optimizer_state(iterations=t_global)
     if best_w is not None:
