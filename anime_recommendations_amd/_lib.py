@@ -106,6 +106,8 @@ PROTOTYPES = {
     "anirec_cosine_topk": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "anirec_topk_mfma_workspace_bytes": (_sz, [_i32, _i32]),
     "anirec_cosine_topk_mfma": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "anirec_cosine_topk_mfma_prior": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, C.c_float, _vp, _vp, _vp, _vp, _sz,
+                                                _vp]),
     "anirec_topk_mfma_timing": (C.c_int, [_i32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "anirec_predict_pairs": (C.c_int, [_vp, _vp, _vp, _vp, _i32, C.POINTER(Head), _vp, _vp]),
     "anirec_predict_workspace_bytes": (_sz, [_i32, _i32, _i32]),

@@ -200,7 +200,9 @@ __device__ __forceinline__ void refresh_row(const CandArgs &a, uint2 *cand_row, 
     for (int j = 0; j < kSlots; ++j) cge += __popcll(__ballot(u[j] >= trial));
     if (cge >= a.k_eff) prefix = trial;
   }
-  const float th = key2f(prefix) - 2.f * kEpsMfma;
+  // never below what the row already uses: thresholds only rise along the key stream, and a caller's prior (a
+  // guess of the final threshold; the re-rank proves or refutes it per row) must survive the early refreshes
+  const float th = fmaxf(key2f(prefix) - 2.f * kEpsMfma, a.theta[row]);
   int nc = 0;
   const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
@@ -541,12 +543,12 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
   }
 }
 
-__global__ void k_init_rows(int32_t *cnt, float *theta, int32_t *flags, int nq, int32_t *unnorm) {
+__global__ void k_init_rows(int32_t *cnt, float *theta, int32_t *flags, int nq, int32_t *unnorm, float theta0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0 && unnorm) *unnorm = 0;
   if (i < nq) {
     cnt[i] = 0;
-    theta[i] = kThetaInit;
+    theta[i] = theta0;  // kThetaInit, or the caller's prior (a lower bound of most rows' final threshold)
     flags[i] = 0;
   }
 }
@@ -932,7 +934,16 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
                             const uint8_t *keep, int32_t exclude_self, int32_t k, int32_t *out_idx,
                             float *out_score, int32_t *flags_out, void *workspace,
                             size_t workspace_bytes, void *stream) {
+  return anirec_cosine_topk_mfma_prior(What, n, queries, nq, keep, exclude_self, k, kThetaInit, out_idx, out_score,
+                                       flags_out, workspace, workspace_bytes, stream);
+}
+
+int anirec_cosine_topk_mfma_prior(const float *What, int32_t n, const int32_t *queries, int32_t nq,
+                                  const uint8_t *keep, int32_t exclude_self, int32_t k, float theta0,
+                                  int32_t *out_idx, float *out_score, int32_t *flags_out, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
   if (!What || !queries || !out_idx || !out_score || !flags_out || !workspace) return ANIREC_EINVAL;
+  if (!(theta0 >= kThetaInit && theta0 <= 1.0f)) return ANIREC_EINVAL;
   if (n < 1 || nq < 0 || k < 1 || k > ANIREC_MAX_TOPK - 1) return ANIREC_EINVAL;
   if (nq == 0) return ANIREC_OK;
   if (workspace_bytes < anirec_topk_mfma_workspace_bytes(n, nq)) return ANIREC_EWORKSPACE;
@@ -956,7 +967,7 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
   int32_t *unnorm = (int32_t *)(p + 64);  // inside the 256 spare bytes
   int32_t *cnt2 = (int32_t *)(p + 256);
   ANIREC_HIP_CHECK(hipMemsetAsync(cnt2, 0, (size_t)nq * kMaxSplit * 4, s));
-  hipLaunchKernelGGL(k_init_rows, dim3((nq + 255) / 256), dim3(256), 0, s, cnt, theta, flags_out, nq, unnorm);
+  hipLaunchKernelGGL(k_init_rows, dim3((nq + 255) / 256), dim3(256), 0, s, cnt, theta, flags_out, nq, unnorm, theta0);
   hipLaunchKernelGGL(k_to_f16, dim3(b1), dim3(256), 0, s, What, nullptr, n, (int)padded_keys(n), keep, 0, Wb, unnorm);
   hipLaunchKernelGGL(k_to_f16, dim3(b2), dim3(256), 0, s, What, queries, nq, nq, nullptr, 1, Qb, unnorm);
   ANIREC_HIP_CHECK(hipGetLastError());
@@ -1064,7 +1075,8 @@ int anirec_predict_topk_mfma(const float *U, const float *A, int32_t n_anime, co
   if (b2 > 8192) b2 = 8192;
   hipLaunchKernelGGL(k_norm_f16, dim3(b1), dim3(256), 0, s, A, nullptr, n_anime, (int)padded_keys(n_anime), 1.0f, Ah, Wb);
   hipLaunchKernelGGL(k_norm_f16, dim3(b2), dim3(256), 0, s, U, users, n_users, n_users, sign, Uh, Qb);
-  hipLaunchKernelGGL(k_init_rows, dim3((n_users + 255) / 256), dim3(256), 0, s, cnt, theta, flags_out, n_users, nullptr);
+  hipLaunchKernelGGL(k_init_rows, dim3((n_users + 255) / 256), dim3(256), 0, s, cnt, theta, flags_out, n_users, nullptr,
+                     kThetaInit);
   ANIREC_HIP_CHECK(hipGetLastError());
   CandArgs ca;
   ca.Qb = (const uint4 *)Qb;

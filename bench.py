@@ -257,15 +257,11 @@ def _cosine_leg(W, nq, k, cpu_baseline, reps=3, slice_note=None, traffic_name=No
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     flops = 2.0 * nq * n * 128
-    # roofline leg: HIP events around the k_cand launches (on the stream they run on), one extra call; with more
-    # than 131 072 queries the op runs in query batches and the hook reports the LAST batch, so time batch by batch
-    cand_ms, cand_launches = 0.0, 0
-    for q0 in range(0, nq, 131072):
-        ops.topk_mfma_timing(True)
-        ops.cosine_topk_mfma(Wh, q[q0:q0 + 131072], k)
-        ms, nl = ops.topk_mfma_timing(False)
-        cand_ms += ms
-        cand_launches += nl
+    # roofline leg: HIP events around the k_cand launches (on the stream they run on) of one extra call of the whole
+    # op — every query batch, with the threshold prior the later batches get from the first one
+    acc = {}
+    ops.cosine_topk_mfma(Wh, q, k, cand_timing=acc)
+    cand_ms, cand_launches = acc.get("ms", 0.0), acc.get("launches", 0)
     tfk = flops / (cand_ms * 1e-3) / 1e12
     # HBM bytes of all k_cand launches of ONE call of the profiled run (scripts/time_topk.py makes 3 calls; the
     # 350 k-key profiles are a 65 536-query slice), scaled to this leg's query count

@@ -244,6 +244,15 @@ int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries
                             const uint8_t *keep, int32_t exclude_self, int32_t k, int32_t *out_idx,
                             float *out_score, int32_t *flags, void *workspace,
                             size_t workspace_bytes, void *stream);
+/* The same with a PRIOR theta0 for every row's threshold (anirec_cosine_topk_mfma uses -4, below every cosine): a
+ * candidate must score >= max(theta0, what the keys seen so far prove).  A good guess of the rows' final k-th best
+ * score (minus a margin) spares most of the ~k ln(n) early appends per row.  Results stay exact: a row whose true
+ * threshold lies below theta0 ends with too few candidates, is flagged like any other unproven row, and the caller
+ * re-runs it (without a prior, or through anirec_cosine_topk).  -4 <= theta0 <= 1. */
+int anirec_cosine_topk_mfma_prior(const float *What, int32_t n, const int32_t *queries, int32_t nq,
+                                  const uint8_t *keep, int32_t exclude_self, int32_t k, float theta0,
+                                  int32_t *out_idx, float *out_score, int32_t *flags, void *workspace,
+                                  size_t workspace_bytes, void *stream);
 /* Measurement hook (bench.py's roofline leg): returns the summed HIP-event duration [ms] and the
  * number of the MFMA candidate-kernel launches of the LAST anirec_cosine_topk_mfma call made while
  * armed, then arms (enable != 0) or disarms the timing.  Armed calls block until the stream drains. */

@@ -331,3 +331,28 @@ def test_key_range_splits_give_the_same_lists(k, monkeypatch):
         assert torch.equal(idx, ref[0]) and torch.equal(sim, ref[1]), sp
     ei, es = ops.cosine_topk(Wh, q[:256], k)
     assert torch.equal(ref[0][:256], ei) and torch.equal(ref[1][:256], es)
+
+
+def test_threshold_prior_learnt_from_the_first_batch(monkeypatch):
+    """Several query batches: the first runs without a prior, its k-th best scores give the others one.  Clustered rows
+    (k-th neighbour at cosine ~0.9) set a high prior; the scattered rows in the later batch (k-th neighbour ~0.3)
+    come out unproven under it and are re-run without — the lists must equal the exact path's, with and without."""
+    from anime_recommendations_amd import ops
+    rng = np.random.default_rng(12)
+    n, k = 30_000, 50
+    centres = rng.normal(0, 1, (60, 128))
+    W = centres[rng.integers(0, 60, n)] + 0.25 * rng.normal(0, 1, (n, 128))
+    W[-700:] = rng.normal(0, 1, (700, 128))                 # scattered rows, all in the second batch
+    Wh = ops.rownorm(torch.from_numpy(W.astype(np.float32)))
+    q = torch.arange(n, dtype=torch.int32, device="cuda")
+    monkeypatch.setenv("ANIREC_TOPK_PRIOR", "0")
+    i0, s0, _ = ops.cosine_topk_mfma(Wh, q, k, batch=16384)
+    monkeypatch.setenv("ANIREC_TOPK_PRIOR", "1")
+    i1, s1, _ = ops.cosine_topk_mfma(Wh, q, k, batch=16384)
+    assert torch.equal(i0, i1) and torch.equal(s0, s1)
+    probe = torch.cat([q[:300], q[16384:16684], q[-700:]])
+    ei, es = ops.cosine_topk(Wh, probe, k)
+    assert torch.equal(i1[probe.long()], ei) and torch.equal(s1[probe.long()], es)
+    # an explicit prior above every score: every row is unproven, re-run, and still right
+    i2, s2, _ = ops.cosine_topk_mfma(Wh, q[:2000], k, prior=0.999)
+    assert torch.equal(i2, i0[:2000]) and torch.equal(s2, s0[:2000])
