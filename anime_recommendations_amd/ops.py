@@ -103,7 +103,7 @@ def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=13107
     window is proven for unit vectors; the kernel checks it and un-normalised input sends EVERY query to the
     exact path (correct, slow).
     ``prior``: a threshold every row starts from instead of "below every cosine" (``None``), a float, or "auto":
-    when the queries come in several batches, the k-th best scores of the FIRST batch's rows (run without a prior)
+    for 49 152 queries or more a first batch of 16 384 rows runs without a prior and the k-th best scores of its rows
     give one for the others — their 0.5 % quantile minus the error window and a margin — which spares those rows
     most of their ~k ln(n) early candidates (k = 100, 350 k keys: 6.7 -> 5.1 ms of MFMA kernel per 65 536 rows).
     A row whose own threshold lies below the prior comes out unproven and is re-run without one.  Results are
@@ -133,11 +133,12 @@ def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=13107
     bq = min(nq, int(batch))
     ws = torch.empty(int(lib.anirec_topk_mfma_workspace_bytes(n, max(bq, 1))), dtype=torch.uint8, device=dev)
     flags = torch.empty(max(bq, 1), dtype=torch.int32, device=dev)
-    # batch boundaries; when a prior is to be learnt the first batch is one round of workgroups (65 536 rows) so that
-    # as many rows as possible run with it
+    # batch boundaries; when a prior is to be learnt the first batch is small — 16 384 rows: 64 workgroups, which the
+    # key-range splits spread over the chip — so that as many rows as possible run with it, and the second one
+    # completes a round of 65 536
     starts = list(range(0, nq, bq))
-    if learn and nq > bq and bq > 65536:
-        starts = [0] + list(range(65536, nq, bq))
+    if learn and nq >= 49152 and bq >= 65536:
+        starts = [0, 16384] + list(range(65536, nq, bq))
     for bi, q0 in enumerate(starts):
         cnt = (starts[bi + 1] if bi + 1 < len(starts) else nq) - q0
         qs = q[q0:q0 + cnt]
