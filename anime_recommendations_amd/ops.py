@@ -128,7 +128,8 @@ def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=13107
         keep_t = torch.as_tensor(keep, device=dev).to(torch.uint8).contiguous()
     theta0 = None if prior in (None, "auto") else float(prior)
     # (small k: a row appends few candidates anyway and the prior buys nothing)
-    learn = prior == "auto" and k >= 32 and os.environ.get("ANIREC_TOPK_PRIOR", "1") != "0"
+    learn = (prior == "auto" and k >= int(os.environ.get("ANIREC_TOPK_PRIOR_MIN_K", "32"))
+             and os.environ.get("ANIREC_TOPK_PRIOR", "1") != "0")
     n_fb = 0
     bq = min(nq, int(batch))
     ws = torch.empty(int(lib.anirec_topk_mfma_workspace_bytes(n, max(bq, 1))), dtype=torch.uint8, device=dev)
