@@ -19,7 +19,8 @@ CHUNK = 32
 ADAM_BLOCKS = 8192
 MAX_TOPK = 128
 MAX_SEG = 16
-ABI_VERSION = 2
+ABI_VERSION = 3
+TOPK_MAX_BATCHES = 64
 
 
 class AnirecError(RuntimeError):
@@ -89,7 +90,7 @@ PROTOTYPES = {
     "anirec_train_bwd": (C.c_int, [_DP, _vp]),
     "anirec_train_adam": (C.c_int, [_DP, _vp]),
     "anirec_train_adam_part": (C.c_int, [_DP, _i32, _vp]),
-    "anirec_train_stage_time": (C.c_int, [_DP, _i32, _i32, C.POINTER(C.c_float), _vp]),
+    "anirec_train_stage_ticks": (C.c_int, [_DP, _i32, C.POINTER(C.c_float), _vp]),
     "anirec_dist_stepper_create": (C.c_int, [_DP, C.POINTER(_vp)]),
     "anirec_dist_stepper_destroy": (C.c_int, [_vp]),
     "anirec_dist_step_mid": (C.c_int, [_vp, _vp]),
@@ -108,6 +109,11 @@ PROTOTYPES = {
     "anirec_cosine_topk_mfma": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "anirec_cosine_topk_mfma_prior": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, C.c_float, _vp, _vp, _vp, _vp, _sz,
                                                 _vp]),
+    "anirec_cosine_topk_job_plan": (C.c_int, [_i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                              C.POINTER(C.c_int32)]),
+    "anirec_cosine_topk_job_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "anirec_cosine_topk_job": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, C.c_float, C.POINTER(C.c_int32), _i32,
+                                         _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "anirec_topk_mfma_timing": (C.c_int, [_i32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "anirec_predict_pairs": (C.c_int, [_vp, _vp, _vp, _vp, _i32, C.POINTER(Head), _vp, _vp]),
     "anirec_predict_workspace_bytes": (_sz, [_i32, _i32, _i32]),

@@ -57,6 +57,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <vector>
 
 #include "anirec_dev.hpp"
@@ -218,9 +219,7 @@ __device__ __forceinline__ void refresh_row(const CandArgs &a, uint2 *cand_row, 
   }
 }
 
-__global__ __launch_bounds__(64) void k_refresh(CandArgs a) {
-  const int lane = threadIdx.x;
-  const int row = blockIdx.x;
+__device__ __forceinline__ void refresh_one(const CandArgs &a, int row, int lane) {
   uint2 *cand_row = a.cand + (size_t)row * kCap;
   int c = min(a.cnt[row], kCap);
   {  // fold what a split super-step left in the regions behind the kept entries (all regions are read before
@@ -262,6 +261,14 @@ __global__ __launch_bounds__(64) void k_refresh(CandArgs a) {
     refresh_row<4>(a, cand_row, row, c, lane);
   else
     refresh_row<kCap / 64>(a, cand_row, row, c, lane);
+}
+
+// One wave per row; the grid is bounded by the host (side_grid) and strides over the rows, so that these waves —
+// which run BESIDE another chain's k_cand in a job — never hold more than a few wave slots per CU: an unbounded
+// grid of one-wave workgroups takes every slot a finished MFMA workgroup frees, and the next 8-wave k_cand workgroup
+// (2 x 160 VGPRs per SIMD + 64 KB of LDS at once) cannot start until the whole side kernel has drained.
+__global__ __launch_bounds__(64) void k_refresh(CandArgs a) {
+  for (int row = blockIdx.x; row < a.nq; row += gridDim.x) refresh_one(a, row, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------
@@ -543,13 +550,81 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
   }
 }
 
-__global__ void k_init_rows(int32_t *cnt, float *theta, int32_t *flags, int nq, int32_t *unnorm, float theta0) {
+// theta0_dev (optional): the prior learnt on the device from the first batch (k_learn_prior); else `theta0`
+__global__ void k_init_rows(int32_t *cnt, int32_t *cnt2, float *theta, int32_t *flags, int nq, int32_t *unnorm, float theta0,
+                            const float *theta0_dev) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0 && unnorm) *unnorm = 0;
   if (i < nq) {
     cnt[i] = 0;
-    theta[i] = theta0;  // kThetaInit, or the caller's prior (a lower bound of most rows' final threshold)
+    *reinterpret_cast<int4 *>(cnt2 + (size_t)i * kMaxSplit) = make_int4(0, 0, 0, 0);
+    theta[i] = theta0_dev ? theta0_dev[0] : theta0;  // kThetaInit, or a prior (a lower bound of most rows' final threshold)
     flags[i] = 0;
+  }
+}
+
+// The threshold prior of the later query batches, learnt on the device from the rows of the first one (no host
+// round trip between the batches): tau[r] = score[r * k + k - 1] is the exact k-th best score of row r; the prior is
+// the lower edge of the 1/1024-wide score bin that holds their 0.5 % quantile, minus the error window and a margin.
+// NaN rows (unproven: re-run later) are skipped; with fewer than 4096 proven rows there is no prior (kThetaInit).
+constexpr int kPriorBins = 2048;  // scores in [-1, 1)
+__global__ __launch_bounds__(1024) void k_learn_prior(const float *score, int rows, int k, float *theta0_dev) {
+  __shared__ int hist[kPriorBins];
+  __shared__ int wsum[16];
+  __shared__ int total_s, bin_s;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < kPriorBins; i += 1024) hist[i] = 0;
+  if (tid == 0) bin_s = -1;
+  __syncthreads();
+  int mine = 0;
+  for (int r = tid; r < rows; r += 1024) {
+    const float t = score[(size_t)r * k + (k - 1)];
+    if (t == t) {
+      int b = (int)floorf((t + 1.0f) * (kPriorBins / 2));
+      b = b < 0 ? 0 : (b >= kPriorBins ? kPriorBins - 1 : b);
+      atomicAdd(&hist[b], 1);
+      ++mine;
+    }
+  }
+  {
+    int v = mine;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((tid & 63) == 0) wsum[tid >> 6] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int t = 0;
+    for (int w = 0; w < 16; ++w) t += wsum[w];
+    total_s = t;
+  }
+  __syncthreads();
+  const int total = total_s;
+  if (total < 4096) {
+    if (tid == 0) theta0_dev[0] = kThetaInit;
+    return;
+  }
+  const int rank = total / 200;  // 0.5 % from below
+  // two bins per thread: exclusive prefix of the histogram, the bin where it crosses `rank`
+  const int h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
+  int inc = h0 + h1;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if ((tid & 63) >= o) inc += t;
+  }
+  __syncthreads();
+  if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+  const int ex0 = base + inc - (h0 + h1), ex1 = ex0 + h0;
+  if (h0 > 0 && ex0 <= rank && rank < ex0 + h0) bin_s = 2 * tid;
+  if (h1 > 0 && ex1 <= rank && rank < ex1 + h1) bin_s = 2 * tid + 1;
+  __syncthreads();
+  if (tid == 0) {
+    const float edge = (float)bin_s * (2.0f / kPriorBins) - 1.0f;
+    theta0_dev[0] = fmaxf(edge - 8.1e-3f, kThetaInit);
   }
 }
 
@@ -581,12 +656,7 @@ constexpr int kMaxSurv = 256;
 // k survivors lie strictly above that bound (a few ulps of slack for the fast exp); saturated heads and
 // worst-case MFMA errors fail the test and fall back to the exact path.
 template <bool kPredict>
-__global__ __launch_bounds__(64) void k_rerank(RerankArgs a) {
-  __shared__ float qs[kDim];
-  __shared__ int32_t sidx[kMaxSurv];
-  __shared__ float sval[kMaxSurv];
-  const int lane = threadIdx.x;
-  const int row = blockIdx.x;
+__device__ __forceinline__ void rerank_one(const RerankArgs &a, int row, int lane, float *qs, int32_t *sidx, float *sval) {
   const size_t base = (size_t)row * kCap;
   const int c = a.cnt[row];
   const int qrow = kPredict ? -1 : a.qidx[row];
@@ -711,6 +781,17 @@ __global__ __launch_bounds__(64) void k_rerank(RerankArgs a) {
   }
 }
 
+template <bool kPredict>
+__global__ __launch_bounds__(64) void k_rerank(RerankArgs a) {  // bounded grid, strides over the rows (see k_refresh)
+  __shared__ float qs[kDim];
+  __shared__ int32_t sidx[kMaxSurv];
+  __shared__ float sval[kMaxSurv];
+  for (int row = blockIdx.x; row < a.nq; row += gridDim.x) {
+    rerank_one<kPredict>(a, row, threadIdx.x, qs, sidx, sval);
+    __syncthreads();  // the next row rewrites qs / sidx / sval
+  }
+}
+
 __global__ void k_flag_all(int32_t *flags, int nq, int32_t *out_idx, float *out_p, int k) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
@@ -738,8 +819,35 @@ static int g_cand_launches = 0;
 // Super-steps of the key stream: thresholds are fixed inside a launch and refreshed between launches;
 // each super-step doubles the number of keys seen, so a row gains about k_eff new candidates per
 // super-step (the first one, with no threshold yet, must fit the buffer).
+// compute units of the current device (the split heuristic below smooths the wave quantisation of a launch over them)
+static int cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      cus = v;
+    else
+      cus = 256;
+  }
+  return cus;
+}
+
+// mid_ev (optional): recorded on s behind the first super-step that ends at or beyond mid_pct % of the key tiles (the
+// job staggers its chains with it)
+// grid of the one-wave-per-row side kernels: one workgroup per row, or — ANIREC_TOPK_SIDE_WAVES > 0, an experiment
+// knob — at most that many waves per CU striding over the rows (measured and NOT adopted: see the job's comment)
+static int side_grid(int nq) {
+  const char *e = getenv("ANIREC_TOPK_SIDE_WAVES");
+  const int per_cu = e ? atoi(e) : 0;
+  if (per_cu <= 0) return nq;
+  const long long g = (long long)cu_count() * per_cu;
+  return (int)(g < nq ? g : nq);
+}
+
 static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, void *dbg_words,
-                           unsigned long long *stamps, size_t n_waves, hipStream_t s) {
+                           unsigned long long *stamps, size_t n_waves, hipStream_t s, hipEvent_t mid_ev = nullptr,
+                           int mid_pct = 0, bool has_prior = false) {
   const int ntiles = (n + kBN - 1) / kBN;
   // 256-row workgroups once they give every CU one (8 waves per CU either way); 128-row otherwise
   const char *wv = getenv("ANIREC_TOPK_WAVES");
@@ -762,7 +870,9 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
   // step, which must fit the buffer next to the ~2 k_eff it already holds — tripling for small k (fewer
   // launches and refreshes), doubling otherwise
   const char *gp = getenv("ANIREC_TOPK_GROWTH");
-  const int growth_pct = gp ? atoi(gp) : (ca.k_eff <= 32 ? 200 : 100);
+  // (rows that start from a prior append little before their own threshold takes over: longer steps, fewer refreshes)
+  const char *gpp = getenv("ANIREC_TOPK_GROWTH_PRIOR");
+  const int growth_pct = has_prior && gpp ? atoi(gpp) : gp ? atoi(gp) : (ca.k_eff <= 32 ? 200 : 100);
   // the first super-step runs without a threshold and appends every key it sees: keep it as short as
   // the k-th-best estimate allows (>= 4 k_eff keys), at most what the buffer holds
   int first = (4 * ca.k_eff + kBN - 1) / kBN;
@@ -774,7 +884,7 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
   // The same splits smooth the wave quantisation of bigger launches: 391 workgroups on 256 CUs run as two full
   // rounds; cut in three they run as five rounds of a third of the length (1.67).
   const char *spe = getenv("ANIREC_TOPK_SPLITS");
-  const int wg_slots = 256 * (wide ? 1 : 2);
+  const int wg_slots = cu_count() * (wide ? 1 : 2);
   // A row gains about k_eff * growth candidates per super-step, spread over the splits: a region (kReg entries)
   // must hold its share with a wide margin, so few splits are not an option for large k.
   const int min_split = (int)((2.5 * ca.k_eff * growth_pct / 100.0 + kReg - 1) / kReg);
@@ -835,16 +945,19 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
       timed.push_back(ev1);
     }
     // (after the last super-step only to fold the split regions: the re-rank reads one list per row)
-    if (t1 < ntiles || regions_used) hipLaunchKernelGGL(k_refresh, dim3(nq), dim3(64), 0, s, ca);
+    if (t1 < ntiles || regions_used) hipLaunchKernelGGL(k_refresh, dim3(side_grid(nq)), dim3(64), 0, s, ca);
     ANIREC_HIP_CHECK(hipGetLastError());
+    if (mid_ev && (long long)t1 * 100 >= (long long)ntiles * mid_pct) {
+      ANIREC_HIP_CHECK(hipEventRecord(mid_ev, s));
+      mid_ev = nullptr;
+    }
     step = (int)((long long)t1 * growth_pct / 100);  // next super-step: growth_pct % of the tiles seen so far
     if (step < 1) step = 1;
     t0 = t1;
     ++n_launch;
   }
   if (g_time_cand) {  // blocking: only bench.py's roofline leg arms this
-    g_cand_ms = 0.f;
-    g_cand_launches = (int)timed.size() / 2;
+    g_cand_launches += (int)timed.size() / 2;  // summed over the batches of a job until the next arm / disarm
     for (size_t i = 0; i + 1 < timed.size(); i += 2) {
       float ms = 0.f;
       (void)hipEventSynchronize(timed[i + 1]);
@@ -915,6 +1028,8 @@ extern "C" {
 int anirec_topk_mfma_timing(int32_t enable, float *cand_ms, int32_t *launches) {
   if (cand_ms) *cand_ms = g_cand_ms;
   if (launches) *launches = g_cand_launches;
+  g_cand_ms = 0.f;
+  g_cand_launches = 0;
   g_time_cand = enable != 0;
   return ANIREC_OK;
 }
@@ -922,12 +1037,102 @@ int anirec_topk_mfma_timing(int32_t enable, float *cand_ms, int32_t *launches) {
 // Wb holds whole key tiles: rows n .. padded_keys(n)-1 are NaN rows (never candidates)
 static inline size_t padded_keys(int32_t n) { return ((size_t)n + kBN - 1) / kBN * kBN; }
 
-// workspace: Wb (padded_keys(n)*256 B) | Qb (nq*256 B) | cand (nq*kCap*8) | cnt, theta (nq*4 each) | 256 B | cnt2
+// ---- one batch of query rows against the converted keys --------------------------------------------------
+// per-batch buffers ("lane"): Qb (rows*256 B) | cand (rows*kCap*8) | cnt, theta (rows*4 each) | cnt2 (rows*16)
+struct LaneBufs {
+  _Float16 *Qb;
+  uint2 *cand;
+  int32_t *cnt;
+  float *theta;
+  int32_t *cnt2;
+};
+static inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
+static size_t lane_bytes(size_t rows) {
+  return al256(rows * 256) + al256(rows * kCap * 8) + 2 * al256(rows * 4) + al256(rows * kMaxSplit * 4);
+}
+static LaneBufs carve_lane(char *p, size_t rows) {
+  LaneBufs b;
+  b.Qb = (_Float16 *)p;
+  p += al256(rows * 256);
+  b.cand = (uint2 *)p;
+  p += al256(rows * kCap * 8);
+  b.cnt = (int32_t *)p;
+  p += al256(rows * 4);
+  b.theta = (float *)p;
+  p += al256(rows * 4);
+  b.cnt2 = (int32_t *)p;
+  return b;
+}
+
+// rows init -> query rows to fp16 -> super-steps of the key stream -> exact re-rank, all on stream s
+static int run_batch(const float *What, const _Float16 *Wb, int n, const int32_t *queries, int nq, int exclude_self, int k,
+                     float theta0, const float *theta0_dev, const LaneBufs &lb, int32_t *unnorm, bool zero_unnorm,
+                     int32_t *out_idx, float *out_score, int32_t *flags, int mode, void *dbg_words, hipStream_t s,
+                     hipEvent_t mid_ev = nullptr, int mid_pct = 0) {
+  if ((size_t)nq * kCap * 8 >= ((size_t)1 << 32)) return ANIREC_EINVAL;  // 32-bit candidate offsets: batch the queries
+  int b2 = (nq + 7) / 8;
+  if (b2 > 8192) b2 = 8192;
+  hipLaunchKernelGGL(k_init_rows, dim3((nq + 255) / 256), dim3(256), 0, s, lb.cnt, lb.cnt2, lb.theta, flags, nq,
+                     zero_unnorm ? unnorm : nullptr, theta0, theta0_dev);
+  hipLaunchKernelGGL(k_to_f16, dim3(b2), dim3(256), 0, s, What, queries, nq, nq, nullptr, 1, lb.Qb, unnorm);
+  ANIREC_HIP_CHECK(hipGetLastError());
+  CandArgs ca;
+  ca.Qb = (const uint4 *)lb.Qb;
+  ca.Wb = (const uint4 *)Wb;
+  ca.nq = nq;
+  ca.n = n;
+  ca.k_eff = exclude_self ? k + 1 : k;
+  ca.cand = lb.cand;
+  ca.cnt = lb.cnt;
+  ca.cnt2 = lb.cnt2;
+  ca.splits = 1;
+  ca.theta = lb.theta;
+  ca.flags = flags;
+  ca.dbg = nullptr;
+  ca.watched = nullptr;
+  ca.wwords = 0;
+  if (mode == 2) {
+    ca.dbg = (unsigned long long *)dbg_words;
+    (void)hipMemsetAsync(dbg_words, 0, 16, s);
+  }
+  unsigned long long *stamps = nullptr;
+  const size_t n_waves = ((size_t)nq + 255) / 256 * 8;
+  if (mode == 4) {  // diagnostic build with in-kernel stamps
+    ANIREC_HIP_CHECK(hipMalloc((void **)&stamps, n_waves * 32));
+    ca.dbg = stamps;
+  }
+  {
+    const int rc = run_super_steps(ca, n, nq, false, mode, dbg_words, stamps, n_waves, s, mid_ev, mid_pct,
+                                   theta0_dev != nullptr || theta0 > kThetaInit);
+    if (rc) return rc;
+  }
+  RerankArgs ra;
+  ra.What = What;
+  ra.Qf = nullptr;
+  ra.qidx = queries;
+  ra.nq = nq;
+  ra.n = n;
+  ra.k = k;
+  ra.k_eff = exclude_self ? k + 1 : k;
+  ra.exclude_self = exclude_self ? 1 : 0;
+  ra.cand = lb.cand;
+  ra.cnt = lb.cnt;
+  ra.theta = lb.theta;
+  ra.flags = flags;
+  ra.out_idx = out_idx;
+  ra.out_score = out_score;
+  // self exclusion is by key index; without it the query index is only used to fetch the row
+  ra.hs = ra.hb = 0.f;
+  ra.sign = 1.f;
+  ra.unnorm = unnorm;
+  hipLaunchKernelGGL(k_rerank<false>, dim3(side_grid(nq)), dim3(64), 0, s, ra);
+  return (int)hipGetLastError();
+}
+
+// workspace: Wb (padded_keys(n)*256 B) | 256 B {dbg words, unnorm @64, learnt prior @128} | one lane of nq rows
 size_t anirec_topk_mfma_workspace_bytes(int32_t n, int32_t nq) {
   if (n < 1 || nq < 1) return 0;
-  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-  return al(padded_keys(n) * 256) + al((size_t)nq * 256) + al((size_t)nq * kCap * 8) + 2 * al((size_t)nq * 4) + 256 +
-         al((size_t)nq * kMaxSplit * 4);
+  return al256(padded_keys(n) * 256) + 256 + lane_bytes((size_t)nq);
 }
 
 int anirec_cosine_topk_mfma(const float *What, int32_t n, const int32_t *queries, int32_t nq,
@@ -947,82 +1152,222 @@ int anirec_cosine_topk_mfma_prior(const float *What, int32_t n, const int32_t *q
   if (n < 1 || nq < 0 || k < 1 || k > ANIREC_MAX_TOPK - 1) return ANIREC_EINVAL;
   if (nq == 0) return ANIREC_OK;
   if (workspace_bytes < anirec_topk_mfma_workspace_bytes(n, nq)) return ANIREC_EWORKSPACE;
-  if ((size_t)nq * kCap * 8 >= ((size_t)1 << 32)) return ANIREC_EINVAL;  // 32-bit candidate offsets: batch the queries
   hipStream_t s = (hipStream_t)stream;
-  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   char *p = (char *)workspace;
   _Float16 *Wb = (_Float16 *)p;
-  p += al(padded_keys(n) * 256);
-  _Float16 *Qb = (_Float16 *)p;
-  p += al((size_t)nq * 256);
-  uint2 *cand = (uint2 *)p;
-  p += al((size_t)nq * kCap * 8);
-  int32_t *cnt = (int32_t *)p;
-  p += al((size_t)nq * 4);
-  float *theta = (float *)p;
-  p += al((size_t)nq * 4);
-  int b1 = (n + 7) / 8, b2 = (nq + 7) / 8;
+  p += al256(padded_keys(n) * 256);
+  char *misc = p;
+  int32_t *unnorm = (int32_t *)(misc + 64);
+  p += 256;
+  const LaneBufs lb = carve_lane(p, (size_t)nq);
+  int b1 = (n + 7) / 8;
   if (b1 > 8192) b1 = 8192;
-  if (b2 > 8192) b2 = 8192;
-  int32_t *unnorm = (int32_t *)(p + 64);  // inside the 256 spare bytes
-  int32_t *cnt2 = (int32_t *)(p + 256);
-  ANIREC_HIP_CHECK(hipMemsetAsync(cnt2, 0, (size_t)nq * kMaxSplit * 4, s));
-  hipLaunchKernelGGL(k_init_rows, dim3((nq + 255) / 256), dim3(256), 0, s, cnt, theta, flags_out, nq, unnorm, theta0);
+  ANIREC_HIP_CHECK(hipMemsetAsync(misc, 0, 256, s));  // unnorm (and the debug words) before the key pass sets it
   hipLaunchKernelGGL(k_to_f16, dim3(b1), dim3(256), 0, s, What, nullptr, n, (int)padded_keys(n), keep, 0, Wb, unnorm);
-  hipLaunchKernelGGL(k_to_f16, dim3(b2), dim3(256), 0, s, What, queries, nq, nq, nullptr, 1, Qb, unnorm);
   ANIREC_HIP_CHECK(hipGetLastError());
-  CandArgs ca;
-  ca.Qb = (const uint4 *)Qb;
-  ca.Wb = (const uint4 *)Wb;
-  ca.nq = nq;
-  ca.n = n;
-  ca.k_eff = exclude_self ? k + 1 : k;
-  ca.cand = cand;
-  ca.cnt = cnt;
-  ca.cnt2 = cnt2;
-  ca.splits = 1;
-  ca.theta = theta;
-  ca.flags = flags_out;
-  ca.dbg = nullptr;
   const char *dbg = getenv("ANIREC_TOPK_DEBUG");
   const int mode = dbg ? atoi(dbg) : 0;
-  if (mode == 2) {
-    ca.dbg = (unsigned long long *)p;  // the 256 spare bytes at the end of the workspace
-    (void)hipMemsetAsync(p, 0, 16, s);
+  return run_batch(What, Wb, n, queries, nq, exclude_self, k, theta0, nullptr, lb, unnorm, false, out_idx, out_score,
+                   flags_out, mode, misc, s);
+}
+
+// ---- the whole job: many query rows in batches, two (or more) batches in flight ---------------------------
+// The matrix cores idle while a batch's k_refresh / k_rerank run (one wave per row, 15 % of a batch's time at
+// 350 k keys, more than half at 18 k).  Batches are independent, so they are dealt to `lanes` stream-ordered chains
+// (the caller's stream + side streams of a process-wide pool, forked and joined by events: one cross-stream edge
+// per JOB, not per step).
+// What the hardware does with that (round 3, rocprofv3 traces of the 350 k x 350 k top-100 job, interleaved A/B on
+// one box): two chains that start together stay in LOCKSTEP — both in k_cand (each at half speed: an 8-wave k_cand
+// workgroup takes 2 x 160 VGPRs per SIMD and 64 KB of LDS, one per CU), then both in k_refresh.  The gain is the
+// filled tails of the k_cand launches and the overlap of the odd re-rank: 33.2 -> 31.8 ms.  Forcing the chains out
+// of phase (ANIREC_TOPK_STAGGER_PCT: chain 2 starts when chain 1 has passed 20 / 33 / 66 % of its key stream) is
+// SLOWER, 32.4-32.8 ms, and so are three or four chains (32.5-32.7): one-wave side workgroups take every wave slot a
+// finished k_cand workgroup frees, so the next k_cand workgroup of the other chain cannot start on that CU until the
+// side kernel has drained — the kernels serialise per CU instead of overlapping.  Bounding the side kernels' grids
+// (ANIREC_TOPK_SIDE_WAVES = 4 / 8 / 16 waves per CU, rows strided) leaves k_cand its room but makes the side
+// kernels — chains of dependent loads, ballots and an O(survivors^2) rank per wave — 2x slower than they are hidden:
+// 35-39 ms.  And k_cand itself gains nothing from a second resident workgroup: a 128-VGPR build of the no-filter loop
+// (two workgroups, 4 waves per SIMD) ran 7.82 ms per 131 072 queries against 7.80 ms (1.50 PFLOP/s either way): the
+// MFMA loop is pipe- / power-bound, not latency-bound.  Longer super-steps for rows that start from a prior
+// (ANIREC_TOPK_GROWTH_PRIOR 150-1000 %) cost 10-15 % (38-40 ms against 34.8 on that box), shorter ones (35-70 %)
+// 3-8 %: a row's own threshold, refreshed at every doubling, is worth more than the launches it costs.
+constexpr int kMaxLanes = 4;
+struct LanePool {
+  int device = -1;
+  hipStream_t side[kMaxLanes - 1] = {nullptr, nullptr, nullptr};
+  hipEvent_t fork = nullptr;
+  hipEvent_t join[kMaxLanes - 1] = {nullptr, nullptr, nullptr};
+  hipEvent_t mid[kMaxLanes - 1] = {nullptr, nullptr, nullptr};  // chain l passed the stagger point of its first batch
+};
+static LanePool g_pool;
+static std::mutex g_pool_mu;
+
+static int pool_get(LanePool **out) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  int dev = 0;
+  ANIREC_HIP_CHECK(hipGetDevice(&dev));
+  if (g_pool.device == dev) {
+    *out = &g_pool;
+    return ANIREC_OK;
   }
-  unsigned long long *stamps = nullptr;
-  const size_t n_waves = ((size_t)nq + 255) / 256 * 8;
-  if (mode == 4) {  // diagnostic build with in-kernel stamps
-    ANIREC_HIP_CHECK(hipMalloc((void **)&stamps, n_waves * 32));
-    ca.dbg = stamps;
+  if (g_pool.device >= 0) return ANIREC_ENODEVICE;  // one process drives one GPU
+  for (int i = 0; i < kMaxLanes - 1; ++i) {
+    ANIREC_HIP_CHECK(hipStreamCreateWithFlags(&g_pool.side[i], hipStreamNonBlocking));
+    ANIREC_HIP_CHECK(hipEventCreateWithFlags(&g_pool.join[i], hipEventDisableTiming));
+    ANIREC_HIP_CHECK(hipEventCreateWithFlags(&g_pool.mid[i], hipEventDisableTiming));
   }
-  ca.watched = nullptr;
-  ca.wwords = 0;
-  {
-    const int rc = run_super_steps(ca, n, nq, false, mode, p, stamps, n_waves, s);
+  ANIREC_HIP_CHECK(hipEventCreateWithFlags(&g_pool.fork, hipEventDisableTiming));
+  g_pool.device = dev;
+  *out = &g_pool;
+  return ANIREC_OK;
+}
+
+static int default_lanes() {
+  const char *e = getenv("ANIREC_TOPK_LANES");
+  int l = e ? atoi(e) : 2;
+  return l < 1 ? 1 : (l > kMaxLanes ? kMaxLanes : l);
+}
+
+int anirec_cosine_topk_job_plan(int32_t nq, int32_t k, int32_t prior_auto, int32_t max_batch, int32_t lanes,
+                                int32_t *starts_host, int32_t *n_batches_host, int32_t *learn_batches_host) {
+  if (!starts_host || !n_batches_host || !learn_batches_host || nq < 0 || k < 1) return ANIREC_EINVAL;
+  if (max_batch < 1) max_batch = 131072;
+  if (max_batch > 1000000) max_batch = 1000000;  // rows * kCap * 8 < 2^32
+  if (lanes < 1) lanes = default_lanes();
+  if (lanes > kMaxLanes) lanes = kMaxLanes;
+  const char *mk = getenv("ANIREC_TOPK_PRIOR_MIN_K");
+  const char *pe = getenv("ANIREC_TOPK_PRIOR");
+  // (small k: a row appends few candidates anyway and the prior buys nothing)
+  const bool may_learn = prior_auto && k >= (mk ? atoi(mk) : 32) && !(pe && atoi(pe) == 0);
+  int nb = 0, learn = 0, q0 = 0;
+  starts_host[0] = 0;
+  // the learning batch is small — 16 384 rows: 64 workgroups, which the key-range splits spread over the chip — so
+  // that as many rows as possible run with the prior; a caller's smaller `max_batch` learns from its first batch
+  if (may_learn && nq >= 49152 && max_batch >= 65536) {
+    q0 = 16384;
+  } else if (may_learn && max_batch < nq && max_batch >= 16384) {
+    q0 = max_batch;
+  }
+  if (q0 > 0) {
+    learn = 1;
+    starts_host[++nb] = q0;
+  }
+  const int rem = nq - q0;
+  if (rem > 0) {
+    int cnt = (rem + max_batch - 1) / max_batch;
+    // every chain the same number of batches — when there is enough work for two batches in flight to pay (measured:
+    // 350 k x 350 k top-100 33.2 -> 31.8 ms on two chains; the 18 k x 18 k job is faster as ONE batch, 0.66 vs 0.69 ms)
+    if (lanes > 1 && rem >= lanes * 32768) cnt = (cnt + lanes - 1) / lanes * lanes;
+    if (nb + cnt > ANIREC_TOPK_MAX_BATCHES) return ANIREC_EINVAL;
+    int rows = (rem + cnt - 1) / cnt;
+    rows = (rows + 255) / 256 * 256;  // whole 256-row workgroups
+    if (rows > max_batch) rows = max_batch;
+    while (q0 < nq) {
+      q0 = q0 + rows < nq ? q0 + rows : nq;
+      starts_host[++nb] = q0;
+    }
+  }
+  *n_batches_host = nb;
+  *learn_batches_host = learn;
+  return ANIREC_OK;
+}
+
+static int max_batch_rows(const int32_t *starts, int nb) {
+  int m = 0;
+  for (int b = 0; b < nb; ++b) m = starts[b + 1] - starts[b] > m ? starts[b + 1] - starts[b] : m;
+  return m;
+}
+
+// Wb | 256 B misc | `lanes` lanes of `rows` rows
+size_t anirec_cosine_topk_job_workspace_bytes(int32_t n, int32_t max_batch_rows_, int32_t lanes) {
+  if (n < 1 || max_batch_rows_ < 1 || lanes < 1 || lanes > kMaxLanes) return 0;
+  return al256(padded_keys(n) * 256) + 256 + (size_t)lanes * lane_bytes((size_t)max_batch_rows_);
+}
+
+int anirec_cosine_topk_job(const float *What, int32_t n, const int32_t *queries, int32_t nq, const uint8_t *keep,
+                           int32_t exclude_self, int32_t k, int32_t prior_mode, float theta0,
+                           const int32_t *starts_host, int32_t n_batches, int32_t learn_batches, int32_t lanes,
+                           int32_t *out_idx, float *out_score, int32_t *flags_out, void *workspace,
+                           size_t workspace_bytes, void *stream) {
+  if (!What || !queries || !out_idx || !out_score || !flags_out || !workspace || !starts_host) return ANIREC_EINVAL;
+  if (n < 1 || nq < 0 || k < 1 || k > ANIREC_MAX_TOPK - 1) return ANIREC_EINVAL;
+  if (prior_mode < 0 || prior_mode > 2 || lanes < 1 || lanes > kMaxLanes) return ANIREC_EINVAL;
+  if (prior_mode == 2 && !(theta0 >= kThetaInit && theta0 <= 1.0f)) return ANIREC_EINVAL;
+  if (n_batches < 0 || n_batches > ANIREC_TOPK_MAX_BATCHES || learn_batches < 0 || learn_batches > 1 ||
+      learn_batches > n_batches)
+    return ANIREC_EINVAL;
+  if (nq == 0 || n_batches == 0) return nq == 0 ? ANIREC_OK : ANIREC_EINVAL;
+  if (starts_host[0] != 0 || starts_host[n_batches] != nq) return ANIREC_EINVAL;
+  for (int b = 0; b < n_batches; ++b)
+    if (starts_host[b + 1] <= starts_host[b]) return ANIREC_EINVAL;
+  if (prior_mode != 1) learn_batches = 0;
+  const int rows = max_batch_rows(starts_host, n_batches);
+  if (g_time_cand) lanes = 1;  // the roofline leg times k_cand launches that run alone
+  if (n_batches - learn_batches < lanes) lanes = n_batches - learn_batches > 0 ? n_batches - learn_batches : 1;
+  if (workspace_bytes < anirec_cosine_topk_job_workspace_bytes(n, rows, lanes)) return ANIREC_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  LanePool *pool = nullptr;
+  if (lanes > 1) {
+    const int rc = pool_get(&pool);
     if (rc) return rc;
   }
-  RerankArgs ra;
-  ra.What = What;
-  ra.Qf = nullptr;
-  ra.qidx = queries;
-  ra.nq = nq;
-  ra.n = n;
-  ra.k = k;
-  ra.k_eff = exclude_self ? k + 1 : k;
-  ra.exclude_self = exclude_self ? 1 : 0;
-  ra.cand = cand;
-  ra.cnt = cnt;
-  ra.theta = theta;
-  ra.flags = flags_out;
-  ra.out_idx = out_idx;
-  ra.out_score = out_score;
-  // self exclusion is by key index; without it the query index is only used to fetch the row
-  ra.hs = ra.hb = 0.f;
-  ra.sign = 1.f;
-  ra.unnorm = unnorm;
-  hipLaunchKernelGGL(k_rerank<false>, dim3(nq), dim3(64), 0, s, ra);
-  return (int)hipGetLastError();
+  char *p = (char *)workspace;
+  _Float16 *Wb = (_Float16 *)p;
+  p += al256(padded_keys(n) * 256);
+  char *misc = p;
+  int32_t *unnorm = (int32_t *)(misc + 64);
+  float *theta0_dev = (float *)(misc + 128);
+  p += 256;
+  LaneBufs lb[kMaxLanes];
+  for (int l = 0; l < lanes; ++l) lb[l] = carve_lane(p + (size_t)l * lane_bytes((size_t)rows), (size_t)rows);
+  int b1 = (n + 7) / 8;
+  if (b1 > 8192) b1 = 8192;
+  ANIREC_HIP_CHECK(hipMemsetAsync(misc, 0, 256, s));
+  hipLaunchKernelGGL(k_to_f16, dim3(b1), dim3(256), 0, s, What, nullptr, n, (int)padded_keys(n), keep, 0, Wb, unnorm);
+  ANIREC_HIP_CHECK(hipGetLastError());
+  const float th_imm = prior_mode == 2 ? theta0 : kThetaInit;
+  const float *th_dev = nullptr;
+  int b = 0;
+  for (; b < learn_batches; ++b) {  // the learning batch runs alone, without a prior
+    const int q0 = starts_host[b], cnt = starts_host[b + 1] - q0;
+    const int rc = run_batch(What, Wb, n, queries + q0, cnt, exclude_self, k, kThetaInit, nullptr, lb[0], unnorm, false,
+                             out_idx + (size_t)q0 * k, out_score + (size_t)q0 * k, flags_out + q0, 0, nullptr, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_learn_prior, dim3(1), dim3(1024), 0, s, out_score + (size_t)q0 * k, cnt, (int)k, theta0_dev);
+    ANIREC_HIP_CHECK(hipGetLastError());
+    th_dev = theta0_dev;
+  }
+  if (lanes > 1) {
+    ANIREC_HIP_CHECK(hipEventRecord(pool->fork, s));
+    for (int l = 1; l < lanes; ++l) ANIREC_HIP_CHECK(hipStreamWaitEvent(pool->side[l - 1], pool->fork, 0));
+  }
+  // ANIREC_TOPK_STAGGER_PCT > 0 (experiment knob, default off): chain l starts its first batch when chain l-1 has
+  // passed that share of the key stream of ITS first batch.
+  const char *sg = getenv("ANIREC_TOPK_STAGGER_PCT");
+  const int stagger = sg ? atoi(sg) : 0;
+  const char *dbg = getenv("ANIREC_TOPK_DEBUG");
+  const int mode = dbg && atoi(dbg) == 1 ? 1 : 0;  // 1: timing-only build of k_cand without the filter
+  for (int i = 0; b < n_batches; ++b, ++i) {
+    const int l = i % lanes;
+    hipStream_t st = l == 0 ? s : pool->side[l - 1];
+    const int q0 = starts_host[b], cnt = starts_host[b + 1] - q0;
+    hipEvent_t mid = nullptr;
+    if (i < lanes && stagger > 0 && lanes > 1) {
+      if (l > 0) ANIREC_HIP_CHECK(hipStreamWaitEvent(st, pool->mid[l - 1], 0));
+      if (l + 1 < lanes && i + 1 < n_batches - learn_batches) mid = pool->mid[l];
+    }
+    const int rc = run_batch(What, Wb, n, queries + q0, cnt, exclude_self, k, th_imm, th_dev, lb[l], unnorm, false,
+                             out_idx + (size_t)q0 * k, out_score + (size_t)q0 * k, flags_out + q0, mode, nullptr, st, mid,
+                             stagger);
+    if (rc) return rc;
+  }
+  if (lanes > 1) {
+    for (int l = 1; l < lanes; ++l) {
+      ANIREC_HIP_CHECK(hipEventRecord(pool->join[l - 1], pool->side[l - 1]));
+      ANIREC_HIP_CHECK(hipStreamWaitEvent(s, pool->join[l - 1], 0));
+    }
+  }
+  return ANIREC_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1065,7 +1410,6 @@ int anirec_predict_topk_mfma(const float *U, const float *A, int32_t n_anime, co
   float *theta = (float *)p;
   p += al((size_t)n_users * 4);
   int32_t *cnt2 = (int32_t *)(p + 256);
-  ANIREC_HIP_CHECK(hipMemsetAsync(cnt2, 0, (size_t)n_users * kMaxSplit * 4, s));
   // sigmoid(gamma*(w*c+b-mu)/sqrt(var+eps)+beta) = sigmoid(c*hs + hb), folded exactly as the exact path does
   float hs, hb;
   head_affine_f32(head, &hs, &hb);
@@ -1075,8 +1419,8 @@ int anirec_predict_topk_mfma(const float *U, const float *A, int32_t n_anime, co
   if (b2 > 8192) b2 = 8192;
   hipLaunchKernelGGL(k_norm_f16, dim3(b1), dim3(256), 0, s, A, nullptr, n_anime, (int)padded_keys(n_anime), 1.0f, Ah, Wb);
   hipLaunchKernelGGL(k_norm_f16, dim3(b2), dim3(256), 0, s, U, users, n_users, n_users, sign, Uh, Qb);
-  hipLaunchKernelGGL(k_init_rows, dim3((n_users + 255) / 256), dim3(256), 0, s, cnt, theta, flags_out, n_users, nullptr,
-                     kThetaInit);
+  hipLaunchKernelGGL(k_init_rows, dim3((n_users + 255) / 256), dim3(256), 0, s, cnt, cnt2, theta, flags_out, n_users,
+                     nullptr, kThetaInit, nullptr);
   ANIREC_HIP_CHECK(hipGetLastError());
   CandArgs ca;
   ca.Qb = (const uint4 *)Qb;
@@ -1122,7 +1466,7 @@ int anirec_predict_topk_mfma(const float *U, const float *A, int32_t n_anime, co
     hipLaunchKernelGGL(k_flag_all, dim3((n_users + 255) / 256), dim3(256), 0, s, flags_out, n_users, out_idx, out_p, k);
     return (int)hipGetLastError();
   }
-  hipLaunchKernelGGL(k_rerank<true>, dim3(n_users), dim3(64), 0, s, ra);
+  hipLaunchKernelGGL(k_rerank<true>, dim3(side_grid(n_users)), dim3(64), 0, s, ra);
   return (int)hipGetLastError();
 }
 

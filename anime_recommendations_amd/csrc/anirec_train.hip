@@ -62,6 +62,7 @@ struct TrainWs {
   size_t hpart_stride;          // floats per parity
   StepPub *pub;                 // [2] step constants published by head workgroup 0
   int32_t *sel;                 // step index of the last head launch (read by bwd / densify / adam)
+  unsigned long long *ticks;    // [4][ANIREC_ADAM_BLOCKS][2] measurement stamps (fwd, head, bwd, adam), behind the arena
   float *regpart;               // [2][2][ANIREC_ADAM_BLOCKS]: user-row / anime-row sum(W^2) partials
   float *P;                     // [2][2*capC][128] chunk partial rows
   float *S;                     // [2][2*capC]      chunk self-coefficient sums
@@ -105,6 +106,7 @@ __host__ inline TrainWs carve(void *base, int cap, int arena_steps) {
   w.slot_bytes = align_up(16) + 2 * align_up(sizeof(int32_t) * 2 * (size_t)cap) +
                  align_up(sizeof(int4) * 2 * (size_t)w.capC);
   w.arena = take(w.slot_bytes * (size_t)arena_steps);
+  w.ticks = (unsigned long long *)take(sizeof(unsigned long long) * 4 * 2 * ANIREC_ADAM_BLOCKS);
   w.total = off;
   return w;
 }
@@ -354,7 +356,20 @@ struct FwdArgs {
   int32_t *pk_count;
   float *su, *sa;
   int cap;
+  unsigned long long *ticks;  // measurement hook: [gridDim.x][2] start / end stamps per workgroup, or nullptr
 };
+
+// Measurement hook (bench.py): every workgroup leaves the 100 MHz constant-clock time of its first and last
+// instruction; a kernel's duration is max(end) - min(start) over its workgroups — taken IN the step, on the batch the
+// step really reads, with whatever the previous kernel left in the caches.
+__device__ __forceinline__ void tick(unsigned long long *ticks, int which) {
+  if (ticks == nullptr) return;  // kernel-uniform
+  if (which) {                   // the end stamp covers every wave of the workgroup and its stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ticks[2 * (size_t)blockIdx.x + which] = __builtin_amdgcn_s_memrealtime();
+}
 
 // One half-wave per rating.  Returns dot products through references; all 32 lanes of
 // the half hold the totals.
@@ -381,10 +396,11 @@ __device__ __forceinline__ int ld_i32(const int32_t *p) {
   return __hip_atomic_load(const_cast<int32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// the forward pass of one workgroup: 8 ratings, a half-wave each
+// the forward pass of one workgroup: a half-wave per rating
 __device__ __forceinline__ void fwd_block(const FwdArgs &a, const anirec_step sc, int vblk) {
   const int nb = min(sc.count, a.cap);
-  const int i = vblk * 8 + (threadIdx.x >> 5);
+  const int per_blk = blockDim.x >> 5;
+  const int i = vblk * per_blk + (threadIdx.x >> 5);
   if (vblk == 0 && threadIdx.x == 0) a.pk_count[0] = nb;
   if (i >= nb) return;
   const int l32 = threadIdx.x & 31;
@@ -394,15 +410,19 @@ __device__ __forceinline__ void fwd_block(const FwdArgs &a, const anirec_step sc
   float su, sa, dd;
   pair_dots(reinterpret_cast<const float4 *>(a.W), ur, ar, l32, su, sa, dd);
   if (l32 == 0) {
-    a.pk_c[i] = cos_from_dots(su, sa, dd);
-    a.pk_t[i] = a.rating[g];
+    const float c = cos_from_dots(su, sa, dd);
+    const float t = a.rating[g];
+    a.pk_c[i] = c;
+    a.pk_t[i] = t;
     a.su[i] = su;
     a.sa[i] = sa;
   }
 }
 
 __global__ __launch_bounds__(256) void k_fwd(FwdArgs a) {
+  tick(a.ticks, 0);
   fwd_block(a, a.sched[a.state->step_fwd], blockIdx.x);
+  tick(a.ticks, 1);
 }
 
 // Multi-GPU only: (mean, M2) of this rank's z = w*c + b values, two-pass, written next to the
@@ -449,6 +469,7 @@ struct HeadArgs {
   StepPub *pub;          // [2]
   int32_t *sel;
   float l2;
+  unsigned long long *ticks;
 };
 
 __device__ __forceinline__ float bce_logits(float y, float t) {
@@ -622,9 +643,11 @@ __device__ __forceinline__ void head_block(const HeadArgs &a, const HeadIn in, i
 
 __global__ __launch_bounds__(kHeadThreads) void k_head(HeadArgs a) {
   __shared__ float scratch[kHeadCols * 16];
+  tick(a.ticks, 0);
   const anirec_state *st = a.state;
   const HeadIn in = {st->step_fwd, st->w, st->b, st->gamma, st->beta};
   head_block(a, in, blockIdx.x, gridDim.x, scratch);
+  tick(a.ticks, 1);
 }
 
 // ------------------------------------------------------------------------------------
@@ -644,6 +667,8 @@ struct BwdArgs {
   const float *dy, *su, *sa;
   float *P, *S;
   int32_t *rowmap;
+  int arena_steps;
+  unsigned long long *ticks;
 };
 
 // what one half-wave needs for its chunk, requested as early as possible
@@ -686,14 +711,30 @@ __device__ __forceinline__ void bwd_prefetch(const BwdArgs &a, int slot, int vbl
   }
 }
 
-// mean(d zhat), mean(d zhat * zhat) numerators from the head partials (fixed order); every thread gets both
-__device__ __forceinline__ void bwd_means(const float *hpart, int n_head_blocks, float *scratch, float (&m)[2]) {
-  m[0] = m[1] = 0.f;
-  for (int k = threadIdx.x; k < n_head_blocks; k += 256) {
+// mean(d zhat), mean(d zhat * zhat) numerators from the head partials: every half-wave sums them itself, lane l the
+// partials l, l + 32, ... in that order, then the fixed butterfly — no LDS, no barrier (round 2 reduced them per
+// workgroup through LDS: two barriers that every gather of the kernel had to wait behind)
+struct BwdMeans {
+  float2 v[2];
+};
+__device__ __forceinline__ void bwd_means_issue(const float *hpart, int n_head_blocks, BwdMeans &x) {
+  const int l = threadIdx.x & 31;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int k = l + 32 * q;
+    x.v[q] = k < n_head_blocks ? *reinterpret_cast<const float2 *>(hpart + (size_t)k * kHeadCols) : make_float2(0.f, 0.f);
+  }
+}
+__device__ __forceinline__ void bwd_means_finish(const float *hpart, int n_head_blocks, const BwdMeans &x, float (&m)[2]) {
+  const int l = threadIdx.x & 31;
+  m[0] = x.v[0].x + x.v[1].x;
+  m[1] = x.v[0].y + x.v[1].y;
+  for (int k = l + 64; k < n_head_blocks; k += 32) {  // more than 64 head workgroups: multi-GPU global batches only
     m[0] += hpart[(size_t)k * kHeadCols + 0];
     m[1] += hpart[(size_t)k * kHeadCols + 1];
   }
-  block_sum<2>(m, scratch);
+  m[0] = halfwave_sum(m[0]);
+  m[1] = halfwave_sum(m[1]);
 }
 
 template <int kRows = 8>  // gathered rows in flight per half-wave
@@ -767,18 +808,33 @@ __device__ __forceinline__ void bwd_chunk(const BwdArgs &a, const StepPub &pub, 
 }
 
 __global__ __launch_bounds__(256, 7) void k_bwd(BwdArgs a) {
-  __shared__ float scratch[2 * 16];
-  const int par = a.sel[0] & 1;
-  const StepPub pub = a.pub[par];
-  // Everything this half-wave will need is requested BEFORE the block reduction of the head
-  // partials (a barrier the loads cannot cross): chunk record -> sorted index + other-table row ->
-  // the rating's scalars and the first four rows.  The kernel is a chain of dependent HBM round
-  // trips at this size; this ordering removes one of them.
+  tick(a.ticks, 0);
+  // The kernel is a chain of dependent memory round trips at this size, so nothing waits for more than it needs:
+  // the step index alone gives the arena slot (chunk record -> sorted index + other-table row -> the rating's
+  // scalars and the first four rows are requested at once); both parities' step constants and head partials are
+  // requested WITH the step index and the right ones are picked when it has arrived.
+  const int step = a.sel[0];
+  const StepPub pub0 = a.pub[0], pub1 = a.pub[1];
+  // (the partial count of the OTHER parity bounds nothing: rows past a parity's count are never summed)
+  BwdMeans h0, h1;
+  const int hcap = (int)(a.hpart_stride / kHeadCols);  // partial rows a parity holds
+  bwd_means_issue(a.hpart, hcap, h0);
+  bwd_means_issue(a.hpart + a.hpart_stride, hcap, h1);
+  const int par = step & 1;
   BwdPre x;
-  bwd_prefetch(a, pub.slot, blockIdx.x, x);
+  bwd_prefetch(a, step % a.arena_steps, blockIdx.x, x);
+  const StepPub pub = par ? pub1 : pub0;
+  BwdMeans hm;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int k = (threadIdx.x & 31) + 32 * q;
+    const float2 v = par ? h1.v[q] : h0.v[q];
+    hm.v[q] = k < pub.n_head_blocks ? v : make_float2(0.f, 0.f);
+  }
   float m[2];
-  bwd_means(a.hpart + par * a.hpart_stride, pub.n_head_blocks, scratch, m);
+  bwd_means_finish(a.hpart + par * a.hpart_stride, pub.n_head_blocks, hm, m);
   bwd_chunk(a, pub, par, m, x);
+  tick(a.ticks, 1);
 }
 
 // g += P[c], s += S[c] for c = c0 .. c1-1 IN THAT ORDER (the sums are bit-reproducible), the loads issued kB
@@ -865,6 +921,7 @@ struct AdamArgs {
   size_t hpart_stride;
   float two_l2;
   float *regpart;  // [2][2][ANIREC_ADAM_BLOCKS]
+  unsigned long long *ticks;
 };
 
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -1090,7 +1147,9 @@ __device__ __forceinline__ void adam_body(const AdamArgs &a, int bid, int nblock
 template <bool kNT>
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
   __shared__ float scratch[kHeadCols * 16];
+  tick(a.ticks, 0);
   adam_body<kNT>(a, blockIdx.x, gridDim.x, scratch);
+  tick(a.ticks, 1);
 }
 
 // sum(W^2) partials of the CURRENT weights into both parities (after (re)loading weights, before validation):
@@ -1239,6 +1298,12 @@ static inline float *packet_ptr(const anirec_train_desc *d, int seg) {
   return d->packets + anirec_packet_floats(d->max_batch) * (size_t)seg;
 }
 
+// measurement hook armed (anirec_train_stage_ticks): kernels stamp their workgroups' start / end times
+static bool g_ticks_on = false;
+static inline unsigned long long *ticks_of(const TrainWs &w, int kernel) {
+  return g_ticks_on ? w.ticks + (size_t)kernel * 2 * ANIREC_ADAM_BLOCKS : nullptr;
+}
+
 static FwdArgs fwd_args(const anirec_train_desc *d, const TrainWs &w) {
   FwdArgs a;
   a.W = d->W;
@@ -1255,6 +1320,7 @@ static FwdArgs fwd_args(const anirec_train_desc *d, const TrainWs &w) {
   a.su = w.su;
   a.sa = w.sa;
   a.cap = d->max_batch;
+  a.ticks = ticks_of(w, 0);
   return a;
 }
 
@@ -1284,6 +1350,7 @@ static HeadArgs head_args(const anirec_train_desc *d, const TrainWs &w) {
   a.pub = w.pub;
   a.sel = w.sel;
   a.l2 = d->l2;
+  a.ticks = ticks_of(w, 1);
   return a;
 }
 
@@ -1336,6 +1403,8 @@ static BwdArgs bwd_args(const anirec_train_desc *d, const TrainWs &w) {
   a.P = w.P;
   a.S = w.S;
   a.rowmap = d->rowmap;
+  a.arena_steps = w.arena_steps;
+  a.ticks = ticks_of(w, 2);
   return a;
 }
 
@@ -1386,6 +1455,7 @@ static AdamArgs adam_args(const anirec_train_desc *d, const TrainWs &w) {
   a.hpart_stride = w.hpart_stride;
   a.two_l2 = 2.0f * d->l2;
   a.regpart = w.regpart;
+  a.ticks = ticks_of(w, 3);
   return a;
 }
 
@@ -1514,44 +1584,39 @@ int anirec_train_adam(const anirec_train_desc *d, void *stream) {
   return launch_adam(d, carve(d->workspace, d->max_batch, d->arena_steps), (hipStream_t)stream);
 }
 
-// Measurement hook (bench.py): average duration [ms] of one of the three idempotent stages of the CURRENT step
-// (0 fwd, 1 head, 2 bwd: same inputs -> same outputs however often they run), `reps` launches captured into a
-// throw-away graph and replayed once between two HIP events.  Eager launches from the host cannot time 5-10 us
-// kernels: the host falls behind and the events measure its latency.  Synchronises the stream.
-int anirec_train_stage_time(const anirec_train_desc *d, int32_t stage, int32_t reps, float *avg_ms_host, void *stream) {
+// Measurement hook (bench.py).  While armed, every training kernel launched through this library stamps the
+// constant-clock (100 MHz) time of each workgroup's first and last instruction into the workspace; this call
+// synchronises the stream, returns per kernel (0 fwd or fwd+head, 1 head, 2 bwd, 3 adam) max(end) - min(start) over
+// the workgroups of the launches made since the last call [us; -1 = not launched], clears the stamps and arms
+// (enable != 0) or disarms.  Call it once per step: the stamps of two launches of one kernel would merge.
+int anirec_train_stage_ticks(const anirec_train_desc *d, int32_t enable, float *us4_host, void *stream) {
   int rc = check_desc(d);
   if (rc) return rc;
-  if (!avg_ms_host || reps < 1 || stage < 0 || stage > 2 || !stream) return ANIREC_EINVAL;
-  if (!d->user_idx || !d->anime_idx || !d->rating || !d->sched) return ANIREC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   TrainWs w = carve(d->workspace, d->max_batch, d->arena_steps);
-  hipGraph_t g = nullptr;
-  hipGraphExec_t ex = nullptr;
-  if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) return ANIREC_ECAPTURE;
-  int e = 0;
-  for (int i = 0; i < reps && !e; ++i)
-    e = stage == 0 ? launch_fwd(d, w, s) : stage == 1 ? launch_head(d, w, s) : launch_bwd_only(d, w, s);
-  hipError_t ce = hipStreamEndCapture(s, &g);
-  if (e || ce != hipSuccess || !g || hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
-    if (g) (void)hipGraphDestroy(g);
-    return e ? e : ANIREC_ECAPTURE;
+  const size_t n = (size_t)4 * 2 * ANIREC_ADAM_BLOCKS;
+  if (us4_host) {
+    unsigned long long *h = new (std::nothrow) unsigned long long[n];
+    if (!h) return ANIREC_EINVAL;
+    hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipMemcpy(h, w.ticks, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+      delete[] h;
+      return (int)e;
+    }
+    for (int k = 0; k < 4; ++k) {
+      unsigned long long lo = ~0ull, hi = 0ull;
+      for (int b = 0; b < ANIREC_ADAM_BLOCKS; ++b) {
+        const unsigned long long t0 = h[((size_t)k * ANIREC_ADAM_BLOCKS + b) * 2], t1 = h[((size_t)k * ANIREC_ADAM_BLOCKS + b) * 2 + 1];
+        if (t0 != 0ull && t0 < lo) lo = t0;
+        if (t1 > hi) hi = t1;
+      }
+      us4_host[k] = hi > 0ull && lo != ~0ull && hi >= lo ? (float)((double)(hi - lo) * 0.01) : -1.0f;
+    }
+    delete[] h;
   }
-  (void)hipGraphDestroy(g);
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  float ms = 0.f;
-  hipError_t he = hipEventCreate(&e0);
-  if (he == hipSuccess) he = hipEventCreate(&e1);
-  if (he == hipSuccess) he = hipGraphLaunch(ex, s);          // warm
-  if (he == hipSuccess) he = hipEventRecord(e0, s);
-  if (he == hipSuccess) he = hipGraphLaunch(ex, s);
-  if (he == hipSuccess) he = hipEventRecord(e1, s);
-  if (he == hipSuccess) he = hipEventSynchronize(e1);
-  if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
-  if (e0) (void)hipEventDestroy(e0);
-  if (e1) (void)hipEventDestroy(e1);
-  (void)hipGraphExecDestroy(ex);
-  if (he != hipSuccess) return (int)he;
-  *avg_ms_host = ms / (float)reps;
+  ANIREC_HIP_CHECK(hipMemsetAsync(w.ticks, 0, n * sizeof(unsigned long long), s));
+  g_ticks_on = enable != 0;
   return ANIREC_OK;
 }
 
@@ -1687,7 +1752,7 @@ int anirec_trainer_run(anirec_trainer *t, int32_t first_step, int32_t n_steps, i
   int G = t->d.arena_steps / 2;
   if (G > 32) G = 32;
   int done = 0;
-  const bool graph = use_graph && s != nullptr && G >= 4 && n_steps >= G;
+  const bool graph = use_graph && s != nullptr && G >= 4 && n_steps >= G && !g_ticks_on;  // (stamped steps run eagerly)
   if (graph) {
     if (!t->exec || t->graph_steps != G) {
       if (t->exec) (void)hipGraphExecDestroy(t->exec);

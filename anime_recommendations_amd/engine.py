@@ -223,13 +223,14 @@ class TrainEngine:
     def adam_anime_finish(self):
         _lib.check(self.lib.anirec_train_adam_part(C.byref(self.desc), 2, self._sp()), "anirec_train_adam_part")
 
-    def stage_time(self, stage, reps=50):
-        """Average duration [ms] of `reps` back-to-back launches of an idempotent stage of the current step
-        ("fwd", "head" or "bwd"), timed inside a captured graph (bench.py's per-kernel figures)."""
-        ms = C.c_float(0.0)
-        _lib.check(self.lib.anirec_train_stage_time(C.byref(self.desc), ("fwd", "head", "bwd").index(stage), int(reps),
-                                                    C.byref(ms), self._sp()), "anirec_train_stage_time")
-        return float(ms.value)
+    def stage_ticks(self, enable=True, read=True):
+        """Measurement hook (bench.py): in-kernel constant-clock stamps.  Returns {"fwd", "head", "bwd", "adam"} ->
+        duration [us] of the launches made since the last call (None = not launched), clears the stamps and arms /
+        disarms.  Synchronises."""
+        us = (C.c_float * 4)()
+        _lib.check(self.lib.anirec_train_stage_ticks(C.byref(self.desc), int(bool(enable)), us if read else None,
+                                                     self._sp()), "anirec_train_stage_ticks")
+        return {k: (float(us[i]) if us[i] >= 0 else None) for i, k in enumerate(("fwd", "head", "bwd", "adam"))} if read else None
 
     # ---- multi-GPU step halves: one C call each, the collectives go between them ------------
     def _get_stepper(self):
@@ -340,7 +341,8 @@ def workspace_layout(max_batch, arena_steps):
     lay["slot_sidx"] = 256
     lay["slot_oth"] = 256 + a1
     lay["slot_chunks"] = 256 + 2 * a1
-    lay["total"] = off + lay["slot_bytes"] * arena_steps
+    lay["ticks"] = (off + lay["slot_bytes"] * arena_steps, 8 * 4 * 2 * _lib.ADAM_BLOCKS)
+    lay["total"] = lay["ticks"][0] + lay["ticks"][1]
     return lay
 
 

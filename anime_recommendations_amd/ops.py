@@ -95,21 +95,38 @@ def cosine_topk(What, queries, k, exclude_self=True, keep=None, workspace=None):
     return out_i, out_s
 
 
-def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=131072, fallback=True, prior="auto",
-                     cand_timing=None):
+def topk_job_plan(nq, k, prior="auto", batch=None, lanes=None):
+    """The library's default batch plan of a cosine_topk_mfma job: (starts [n_batches + 1], learn_batches, lanes)."""
+    lib = _lib.load()
+    st = (C.c_int32 * (_lib.TOPK_MAX_BATCHES + 1))()
+    nb, nl = C.c_int32(0), C.c_int32(0)
+    if lanes is None:
+        lanes = int(os.environ.get("ANIREC_TOPK_LANES", "2"))
+    lanes = max(1, min(4, int(lanes)))
+    _lib.check(lib.anirec_cosine_topk_job_plan(int(nq), int(k), int(prior == "auto"), int(batch or 0), lanes, st,
+                                               C.byref(nb), C.byref(nl)), "anirec_cosine_topk_job_plan")
+    return [int(st[i]) for i in range(nb.value + 1)], int(nl.value), lanes
+
+
+def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=None, fallback=True, prior="auto",
+                     cand_timing=None, lanes=None, stats=None):
     """cosine_topk on the matrix cores (fp16 MFMA candidates + exact fp32 re-rank); rows the
     kernel could not prove complete are transparently re-run through the exact kernels.
     ``What`` must hold unit-norm rows (``rownorm`` output, as at every reference call site): the MFMA error
     window is proven for unit vectors; the kernel checks it and un-normalised input sends EVERY query to the
     exact path (correct, slow).
+    The whole job is ONE library call (anirec_cosine_topk_job): keys converted once, the queries cut into batches
+    (``topk_job_plan``; ``batch`` = most rows per batch) that run as ``lanes`` interleaved stream-ordered chains, so
+    the per-row refresh / re-rank work of one batch runs beside the MFMA kernel of another.
     ``prior``: a threshold every row starts from instead of "below every cosine" (``None``), a float, or "auto":
     for 49 152 queries or more a first batch of 16 384 rows runs without a prior and the k-th best scores of its rows
-    give one for the others — their 0.5 % quantile minus the error window and a margin — which spares those rows
-    most of their ~k ln(n) early candidates (k = 100, 350 k keys: 6.7 -> 5.1 ms of MFMA kernel per 65 536 rows).
-    A row whose own threshold lies below the prior comes out unproven and is re-run without one.  Results are
-    identical either way.
+    give one for the others — their 0.5 % quantile minus the error window and a margin, computed on the device —
+    which spares those rows most of their ~k ln(n) early candidates.  A row whose own threshold lies below the prior
+    comes out unproven and is re-run without one.  Results are identical either way.
     ``cand_timing``: a dict that receives ``ms`` / ``launches`` of all MFMA candidate-kernel launches of this call
-    (HIP events on their stream, every batch and re-run included; the call then blocks per batch — bench.py only).
+    (HIP events on their stream, every batch and re-run included; the job then runs on one chain and blocks per
+    batch — bench.py only).  ``stats``: a dict that receives ``batches``, ``learn_batches``, ``lanes``, ``starts``,
+    ``rerun_rows`` (unproven under the prior, run again without) and ``fallback_rows``.
     Returns (idx, score, n_fallback)."""
     _need_gpu()
     lib = _lib.load()
@@ -121,69 +138,60 @@ def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=13107
     nq = int(q.numel())
     out_i = torch.empty(nq, k, dtype=torch.int32, device=dev)
     out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
+    if stats is None:
+        stats = {}
+    stats.update(batches=0, learn_batches=0, rerun_rows=0, fallback_rows=0)
     if nq == 0:                     # an empty query shard (dist_infer on more ranks than queries)
         return out_i, out_s, 0
     keep_t = None
     if keep is not None:
         keep_t = torch.as_tensor(keep, device=dev).to(torch.uint8).contiguous()
-    theta0 = None if prior in (None, "auto") else float(prior)
-    # (small k: a row appends few candidates anyway and the prior buys nothing)
-    learn = (prior == "auto" and k >= int(os.environ.get("ANIREC_TOPK_PRIOR_MIN_K", "32"))
-             and os.environ.get("ANIREC_TOPK_PRIOR", "1") != "0")
+    starts, learn, lanes = topk_job_plan(nq, k, prior, batch, lanes)
+    nb = len(starts) - 1
+    if prior is None:
+        mode, theta0 = 0, 0.0
+    elif prior == "auto":
+        mode, theta0 = (1 if learn else 0), 0.0
+    else:
+        mode, theta0 = 2, float(prior)
+    rows = max(starts[i + 1] - starts[i] for i in range(nb))
+    eff_lanes = max(1, min(lanes, nb - learn))
+    ws = torch.empty(int(lib.anirec_cosine_topk_job_workspace_bytes(n, rows, eff_lanes)), dtype=torch.uint8, device=dev)
+    flags = torch.empty(nq, dtype=torch.int32, device=dev)
+    st = (C.c_int32 * (nb + 1))(*starts)
+    if cand_timing is not None:
+        topk_mfma_timing(True)
+    _lib.check(lib.anirec_cosine_topk_job(_lib.ptr(What), n, _lib.ptr(q), nq, _lib.ptr(keep_t), int(bool(exclude_self)),
+                                          int(k), mode, theta0, st, nb, learn, eff_lanes, _lib.ptr(out_i), _lib.ptr(out_s),
+                                          _lib.ptr(flags), _lib.ptr(ws), ws.numel(), _stream()), "anirec_cosine_topk_job")
+    if cand_timing is not None:
+        ms, nl = topk_mfma_timing(False)
+        cand_timing["ms"] = cand_timing.get("ms", 0.0) + ms
+        cand_timing["launches"] = cand_timing.get("launches", 0) + nl
+    stats.update(batches=nb, learn_batches=learn, lanes=eff_lanes, starts=starts)
+    bad = torch.nonzero(flags, as_tuple=False).flatten()       # the one host sync of the job
     n_fb = 0
-    bq = min(nq, int(batch))
-    ws = torch.empty(int(lib.anirec_topk_mfma_workspace_bytes(n, max(bq, 1))), dtype=torch.uint8, device=dev)
-    flags = torch.empty(max(bq, 1), dtype=torch.int32, device=dev)
-    # batch boundaries; when a prior is to be learnt the first batch is small — 16 384 rows: 64 workgroups, which the
-    # key-range splits spread over the chip — so that as many rows as possible run with it, and the second one
-    # completes a round of 65 536
-    starts = list(range(0, nq, bq))
-    if learn and nq >= 49152 and bq >= 65536:
-        starts = [0, 16384] + list(range(65536, nq, bq))
-    for bi, q0 in enumerate(starts):
-        cnt = (starts[bi + 1] if bi + 1 < len(starts) else nq) - q0
-        qs = q[q0:q0 + cnt]
-        args = (_lib.ptr(out_i[q0:q0 + cnt]), _lib.ptr(out_s[q0:q0 + cnt]), _lib.ptr(flags), _lib.ptr(ws), ws.numel(),
-                _stream())
-        if cand_timing is not None:
-            topk_mfma_timing(True)
-        if theta0 is None:
-            _lib.check(lib.anirec_cosine_topk_mfma(_lib.ptr(What), n, _lib.ptr(qs), cnt, _lib.ptr(keep_t),
-                                                   int(bool(exclude_self)), int(k), *args), "anirec_cosine_topk_mfma")
-        else:
-            _lib.check(lib.anirec_cosine_topk_mfma_prior(_lib.ptr(What), n, _lib.ptr(qs), cnt, _lib.ptr(keep_t),
-                                                         int(bool(exclude_self)), int(k), theta0, *args),
-                       "anirec_cosine_topk_mfma_prior")
-        if cand_timing is not None:
-            ms, nl = topk_mfma_timing(False)
-            cand_timing["ms"] = cand_timing.get("ms", 0.0) + ms
-            cand_timing["launches"] = cand_timing.get("launches", 0) + nl
-        bad = torch.nonzero(flags[:cnt], as_tuple=False).flatten()
-        if bad.numel() and theta0 is not None:
-            # rows the prior was too high for (or otherwise unproven): once more without it
-            fi, fs, nb = cosine_topk_mfma(What, qs[bad], k, exclude_self=exclude_self, keep=keep_t, batch=batch,
-                                          fallback=fallback, prior=None, cand_timing=cand_timing)
-            out_i[q0 + bad] = fi
-            out_s[q0 + bad] = fs
-            n_fb += nb
-            continue
-        if bad.numel():
-            n_fb += int(bad.numel())
-        if bad.numel() and fallback:
-            fi, fs = cosine_topk(What, qs[bad], k, exclude_self=exclude_self, keep=keep_t)
-            out_i[q0 + bad] = fi
-            out_s[q0 + bad] = fs
-        if learn and theta0 is None and q0 + cnt < nq and cnt >= 16384:
-            tau = out_s[q0:q0 + cnt, k - 1]          # exact k-th best score of every row of this batch
-            tau = tau[~torch.isnan(tau)]
-            if tau.numel() >= 4096:
-                theta0 = max(float(torch.quantile(tau[:: max(1, tau.numel() // 65536)], 0.005)) - 8.1e-3, -4.0)
+    if bad.numel() and mode != 0:
+        # rows the prior was too high for (or otherwise unproven): once more without it
+        sub = {}
+        fi, fs, n_fb = cosine_topk_mfma(What, q[bad], k, exclude_self=exclude_self, keep=keep_t, batch=batch,
+                                        fallback=fallback, prior=None, cand_timing=cand_timing, lanes=lanes, stats=sub)
+        out_i[bad] = fi
+        out_s[bad] = fs
+        stats["rerun_rows"] = int(bad.numel())
+    elif bad.numel():
+        n_fb = int(bad.numel())
+        if fallback:
+            fi, fs = cosine_topk(What, q[bad], k, exclude_self=exclude_self, keep=keep_t)
+            out_i[bad] = fi
+            out_s[bad] = fs
+    stats["fallback_rows"] = n_fb
     return out_i, out_s, n_fb
 
 
 def topk_mfma_timing(enable):
-    """Arm / disarm HIP-event timing of the MFMA candidate kernel; returns (ms, launches) of the last
-    armed cosine_topk_mfma call (bench.py's roofline leg)."""
+    """Arm / disarm HIP-event timing of the MFMA candidate kernel; returns (ms, launches) summed over the calls
+    made since it was last armed (bench.py's roofline leg)."""
     lib = _lib.load()
     ms, nl = C.c_float(0.0), C.c_int32(0)
     _lib.check(lib.anirec_topk_mfma_timing(int(bool(enable)), C.byref(ms), C.byref(nl)), "anirec_topk_mfma_timing")

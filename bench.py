@@ -90,7 +90,7 @@ def run_single(workload, steps, warmup, batch, use_graph=True, cpu_baseline=True
     from anime_recommendations_amd.engine import TrainEngine
     n_users, n_anime = WORKLOADS[workload]
     dev = torch.device("cuda:0")
-    total_steps = warmup + 2 * steps          # timed region + instrumented per-kernel pass
+    total_steps = warmup + steps + 80         # timed region + instrumented per-kernel pass
     ui, ai, t = synth_ratings(n_users, n_anime, total_steps * batch, dev)
     U, A = init_tables(n_users, n_anime, dev)
     eng = TrainEngine(n_users, n_anime, max_batch=batch, arena_steps=64)
@@ -110,35 +110,35 @@ def run_single(workload, steps, warmup, batch, use_graph=True, cpu_baseline=True
     rec = eng.read_state()
     assert int(rec["step_fwd"]) == warmup + steps and np.isfinite(rec["last_loss"])
 
-    # instrumented pass over the same K steps' worth of work.  k_adam (the dominant kernel): HIP events on the
-    # engine's stream around every launch, the steps run eagerly stage by stage (the host is far ahead of a 190 us
-    # kernel).  The three small kernels (5-10 us, shorter than an eager launch from Python: events around them
-    # would time the host): each repeated 50 x inside a captured graph on the batch of a prepared step
-    # (anirec_train_stage_time; they are idempotent), sampled at 8 steps of the pass.
-    evs = []
-    small = {"fwd": [], "head": [], "bwd": []}
+    # instrumented pass: the SAME step sequence continued eagerly, every kernel stamping the constant-clock time of each
+    # workgroup's first and last instruction (anirec_train_stage_ticks): a kernel's duration is max(end) - min(start),
+    # taken in the step, on the batch the step really reads, behind whatever the previous kernel left in the caches
+    # (round 2 replayed one batch 50 x: its gathered rows were cache-resident from the second repetition on).
+    # The dominant kernel is ALSO timed by HIP events on the engine's stream (the roofline figure): the host is far
+    # ahead of a 190 us kernel, so the pair brackets the kernel and nothing else.
+    kern = {"fwd": [], "head": [], "bwd": [], "adam_by_stamps": []}
     first = warmup + steps
-    done = 0
-    sample_every = max(1, steps // 8)
-    while done < steps:
-        blk = min(eng.arena_steps, steps - done)
-        eng.prep(first + done, blk)
-        for k in range(blk):
-            eng.fwd()
-            eng.head()
-            eng.bwd()
-            if (done + k) % sample_every == 0:
-                for name in small:
-                    small[name].append(eng.stage_time(name))
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(eng.stream)
-            eng.adam()
-            e1.record(eng.stream)
-            evs.append((e0, e1))
-        done += blk
+    eng.stage_ticks(True, read=False)
+    evs = []
+    n_inst = max(8, min(64, steps // 2))
+    for k in range(n_inst):
+        eng.prep(first + k, 1)
+        eng.fwd()
+        eng.head()
+        eng.bwd()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(eng.stream)
+        eng.adam()
+        e1.record(eng.stream)
+        evs.append((e0, e1))
+        tk = eng.stage_ticks(True)
+        for name in ("fwd", "head", "bwd"):
+            kern[name].append(tk[name])
+        kern["adam_by_stamps"].append(tk["adam"])
+    eng.stage_ticks(False, read=False)
     eng.synchronize()
-    kern_ms = {k: float(np.mean(v)) for k, v in small.items()}
+    kern_ms = {k: float(np.mean(v)) * 1e-3 for k, v in kern.items()}
     kern_ms["adam"] = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     rows = n_users + n_anime
     adam_bytes = ADAM_BYTES_PER_ELEM * rows * 128
@@ -166,7 +166,7 @@ def run_single(workload, steps, warmup, batch, use_graph=True, cpu_baseline=True
         "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_step": step_bytes,
                           "achieved": step_bytes / (dt / steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS,
-                          "sum_of_kernels_ms": float(sum(kern_ms.values()))},
+                          "sum_of_kernels_ms": kern_ms["fwd"] + kern_ms["head"] + kern_ms["bwd"] + kern_ms["adam"]},
         "fwd_gbs": FWD_BYTES_PER_RATING * batch / (kern_ms["fwd"] * 1e-3) / 1e9,
         "bwd_gbs": BWD_BYTES_PER_RATING * batch / (kern_ms["bwd"] * 1e-3) / 1e9,
     }

@@ -30,13 +30,14 @@
 extern "C" {
 #endif
 
-#define ANIREC_ABI_VERSION 2
+#define ANIREC_ABI_VERSION 3
 #define ANIREC_DIM 128          /* embedding width (floats) */
 #define ANIREC_MAX_BATCH 16384  /* ratings per rank per step handled by one sort workgroup */
 #define ANIREC_CHUNK 32         /* max gradient contributions summed by one half-wave */
 #define ANIREC_ADAM_BLOCKS 8192 /* grid of the dense Adam kernel == length of reg partials */
 #define ANIREC_MAX_TOPK 128     /* k limit of the fused top-k kernels */
 #define ANIREC_MAX_SEG 16       /* max head packets (ranks of one node) */
+#define ANIREC_TOPK_MAX_BATCHES 64 /* query batches of one anirec_cosine_topk_job */
 
 enum {
   ANIREC_OK = 0,
@@ -162,9 +163,11 @@ int anirec_train_fwd(const anirec_train_desc *d, void *stream);
 int anirec_train_head(const anirec_train_desc *d, void *stream);
 int anirec_train_bwd(const anirec_train_desc *d, void *stream);
 int anirec_train_adam(const anirec_train_desc *d, void *stream);
-/* Measurement hook (bench.py): average duration [ms] of `reps` back-to-back launches (captured into a graph) of
- * one idempotent stage of the current step — 0 fwd, 1 head, 2 bwd.  Synchronises the stream. */
-int anirec_train_stage_time(const anirec_train_desc *d, int32_t stage, int32_t reps, float *avg_ms_host, void *stream);
+/* Measurement hook (bench.py): while armed, the training kernels stamp each workgroup's first / last instruction
+ * with the 100 MHz constant clock.  Synchronises the stream, writes to us4_host (may be NULL) the duration [us] of
+ * kernel 0 fwd, 1 head, 2 bwd, 3 adam over the launches since the last call (-1 = none),
+ * clears the stamps, then arms (enable != 0) or disarms.  Armed steps never replay the captured graph. */
+int anirec_train_stage_ticks(const anirec_train_desc *d, int32_t enable, float *us4_host, void *stream);
 
 /* adam as two launches (dense_mode 1): which == 1 updates the user rows (may run while the anime gradient is
  * still in the all-reduce), which == 2 the anime rows and finishes the step. */
@@ -253,9 +256,30 @@ int anirec_cosine_topk_mfma_prior(const float *What, int32_t n, const int32_t *q
                                   const uint8_t *keep, int32_t exclude_self, int32_t k, float theta0,
                                   int32_t *out_idx, float *out_score, int32_t *flags, void *workspace,
                                   size_t workspace_bytes, void *stream);
-/* Measurement hook (bench.py's roofline leg): returns the summed HIP-event duration [ms] and the
- * number of the MFMA candidate-kernel launches of the LAST anirec_cosine_topk_mfma call made while
- * armed, then arms (enable != 0) or disarms the timing.  Armed calls block until the stream drains. */
+/* The whole similar_anime / similar_users job (every row a query: similar_users.py:290-312 at BASELINE configs[3]
+ * scale) as ONE call: the keys are converted once, the queries run in batches [starts[b], starts[b+1]), and the
+ * batches are dealt to `lanes` stream-ordered chains (the caller's stream + side streams the library keeps, forked and
+ * joined by events inside this call; 1 <= lanes <= 4) so that one batch's per-row refresh / re-rank waves run beside
+ * another batch's MFMA kernel.  prior_mode 0: no prior; 1: the first `learn_batches` (0 or 1) batches run alone and
+ * the k-th best scores of their rows give the others a prior, computed on the device (no host round trip); 2: theta0.
+ * flags[nq] as for anirec_cosine_topk_mfma: the caller re-runs flagged rows (without a prior, then through
+ * anirec_cosine_topk).  Results are identical to anirec_cosine_topk whatever the plan.
+ * anirec_cosine_topk_job_plan fills the library's default plan: starts_host[ANIREC_TOPK_MAX_BATCHES + 1];
+ * max_batch <= 0 and lanes <= 0 select the defaults (131072 rows; env ANIREC_TOPK_LANES or 2).
+ * workspace: anirec_cosine_topk_job_workspace_bytes(n, rows of the largest batch, lanes). */
+int anirec_cosine_topk_job_plan(int32_t nq, int32_t k, int32_t prior_auto, int32_t max_batch, int32_t lanes,
+                                int32_t *starts_host, int32_t *n_batches_host, int32_t *learn_batches_host);
+size_t anirec_cosine_topk_job_workspace_bytes(int32_t n, int32_t max_batch_rows, int32_t lanes);
+int anirec_cosine_topk_job(const float *What, int32_t n, const int32_t *queries, int32_t nq, const uint8_t *keep,
+                           int32_t exclude_self, int32_t k, int32_t prior_mode, float theta0,
+                           const int32_t *starts_host, int32_t n_batches, int32_t learn_batches, int32_t lanes,
+                           int32_t *out_idx, float *out_score, int32_t *flags, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
+/* Measurement hook (bench.py's roofline leg): returns the summed HIP-event duration [ms] and the number of the
+ * MFMA candidate-kernel launches of the calls made since it was last armed, then arms (enable != 0) or disarms
+ * the timing.  Armed calls block until the stream drains, and an armed job runs its batches on ONE chain so that
+ * every timed launch runs alone. */
 int anirec_topk_mfma_timing(int32_t enable, float *cand_ms, int32_t *launches);
 
 /* ------------------------------------------------------------------------- *

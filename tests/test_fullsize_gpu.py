@@ -115,6 +115,51 @@ def test_350k_neighbour_lists_properties_and_sample_equals_exact_path():
     assert (es.cpu().numpy() == sim[[0, 5, 17, 999, 4095]]).all()
 
 
+def test_350k_allpairs_top100_rows_of_every_batch_equal_the_exact_path():
+    """BASELINE configs[3] users job exactly as bench.py runs it (350 k x 350 k, k = 100, the library's default plan:
+    a 16 384-row learning batch, then prior batches on two interleaved chains; similar_users.py:290-312 for every user).
+    Rows drawn from EVERY batch — first / last row of each, a random sample of each, and rows that come out unproven
+    under the learnt prior and are re-run without it — must equal the exact kernels' lists bit for bit.
+    The bulk of the table lives (almost) in a 64-dimensional subspace (k-th best cosine ~0.43); 360 planted rows are
+    isotropic in all 128 dimensions (k-th best ~0.30, far below the learnt prior): those are the re-run rows."""
+    from anime_recommendations_amd import ops
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    n, k = N_USERS, 100
+    W = torch.randn(n, 128, generator=g, device="cuda") * 0.05
+    W[:, 64:] *= 0.04
+    st0, learn0, _ = ops.topk_job_plan(n, k)
+    assert learn0 == 1 and st0[1] == 16384 and len(st0) >= 5
+    planted = torch.cat([torch.arange(100, 140), torch.arange(st0[1] + 7, st0[1] + 87),
+                         torch.arange(st0[2] - 40, st0[2] + 40), torch.arange(st0[3] + 1000, st0[3] + 1080),
+                         torch.arange(n - 80, n)]).cuda()
+    W[planted] = torch.randn(planted.numel(), 128, generator=g, device="cuda") * 0.05
+    Wh = ops.rownorm(W)
+    q = torch.arange(n, dtype=torch.int32, device="cuda")
+    stats = {}
+    idx, sim, nfb = ops.cosine_topk_mfma(Wh, q, k, stats=stats)
+    starts = stats["starts"]
+    assert starts == st0 and stats["learn_batches"] == 1 and stats["lanes"] == 2
+    late = planted[planted >= starts[1]]
+    assert stats["rerun_rows"] >= late.numel()            # every planted row behind the learning batch was refuted
+    assert stats["rerun_rows"] < 2000 and nfb <= 4
+    rng = np.random.default_rng(5)
+    probe = [planted.cpu().numpy()]
+    for b in range(len(starts) - 1):
+        lo, hi = starts[b], starts[b + 1]
+        probe.append(np.array([lo, lo + 1, hi - 2, hi - 1]))
+        probe.append(rng.integers(lo, hi, 96))
+    probe = torch.from_numpy(np.unique(np.concatenate(probe))).cuda()
+    ei, es = ops.cosine_topk(Wh, probe.to(torch.int32), k)
+    assert torch.equal(idx[probe], ei) and torch.equal(sim[probe], es)
+    # whole-job properties
+    assert bool((idx >= 0).all()) and bool((idx != q[:, None]).all())
+    assert bool((sim[:, 1:] <= sim[:, :-1]).all())
+    # one chain instead of two, and no prior at all: the same lists
+    i1, s1, _ = ops.cosine_topk_mfma(Wh, q[: starts[2]], k, lanes=1)
+    assert torch.equal(i1, idx[: starts[2]]) and torch.equal(s1, sim[: starts[2]])
+
+
 def test_predict_grid_full_anime_table_matches_pairwise_kernel():
     from anime_recommendations_amd import ops
     g = torch.Generator(device="cuda")

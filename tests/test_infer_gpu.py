@@ -356,3 +356,44 @@ def test_threshold_prior_learnt_from_the_first_batch(monkeypatch):
     # an explicit prior above every score: every row is unproven, re-run, and still right
     i2, s2, _ = ops.cosine_topk_mfma(Wh, q[:2000], k, prior=0.999)
     assert torch.equal(i2, i0[:2000]) and torch.equal(s2, s0[:2000])
+
+
+@pytest.mark.parametrize("nq", [49151, 49152])
+def test_job_plan_boundary_learning_batch_on_and_off(nq):
+    """49 152 queries is where the default plan starts to learn a prior from a 16 384-row first batch (below: one plain
+    batch).  All-pairs over 49 152 keys, k = 40: lists equal the exact path's on rows of every batch."""
+    from anime_recommendations_amd import ops
+    g = torch.Generator(device="cuda")
+    g.manual_seed(21)
+    n, k = 49152, 40
+    Wh = ops.rownorm(torch.randn(n, 128, generator=g, device="cuda") * 0.05)
+    q = torch.arange(nq, dtype=torch.int32, device="cuda")
+    stats = {}
+    idx, sim, nfb = ops.cosine_topk_mfma(Wh, q, k, stats=stats)
+    starts = stats["starts"]
+    assert stats["learn_batches"] == (1 if nq >= 49152 else 0)
+    assert starts == ([0, 16384, 49152] if nq >= 49152 else [0, 49151]) and nfb == 0
+    probe = np.unique(np.concatenate([[s_, min(s_ + 1, nq - 1), max(s_ - 1, 0)] for s_ in starts[:-1]] +
+                                     [np.arange(0, nq, 769), [nq - 1]]))
+    probe = torch.from_numpy(probe).cuda()
+    ei, es = ops.cosine_topk(Wh, probe.to(torch.int32), k)
+    assert torch.equal(idx[probe], ei) and torch.equal(sim[probe], es)
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 3, 4])
+def test_job_lanes_give_identical_lists(lanes):
+    """The batches of a job are dealt to 1-4 interleaved stream-ordered chains (side streams forked / joined inside
+    the call): results must not depend on it, run to run either."""
+    from anime_recommendations_amd import ops
+    rng = np.random.default_rng(31)
+    n, k = 20_000, 30
+    Wh = ops.rownorm(torch.from_numpy(rng.normal(0, 0.05, (n, 128)).astype(np.float32)))
+    q = torch.from_numpy(rng.permutation(n).astype(np.int32)).cuda()
+    ref = ops.cosine_topk_mfma(Wh, q, k, lanes=1, batch=20_000)
+    for _ in range(2):
+        stats = {}
+        idx, sim, nfb = ops.cosine_topk_mfma(Wh, q, k, lanes=lanes, batch=2560, prior=None, stats=stats)
+        assert 8 <= stats["batches"] <= 9 and stats["lanes"] == lanes
+        assert torch.equal(idx, ref[0]) and torch.equal(sim, ref[1]) and nfb == ref[2]
+    ei, es = ops.cosine_topk(Wh, q[:300], k)
+    assert torch.equal(ref[0][:300], ei) and torch.equal(ref[1][:300], es)
