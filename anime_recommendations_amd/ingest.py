@@ -141,6 +141,25 @@ class EncodedRatings:
     user_ids: torch.Tensor   # index -> original user_id
     anime_ids: torch.Tensor  # index -> original anime_id
 
+    # the part of data.RatingTable's interface trainer.fit uses: a table that never leaves HBM trains as it is
+    @property
+    def n_users(self):
+        return int(self.user_ids.numel())
+
+    @property
+    def n_anime(self):
+        return int(self.anime_ids.numel())
+
+    def __len__(self):
+        return int(self.user.numel())
+
+    def split(self, test_size):
+        """(train, test) index ranges: the last ``test_size`` shuffled rows are held out (neural_network.py:161-169)."""
+        n_train = len(self) - int(test_size)
+        if n_train <= 0:
+            raise ValueError("test_size %d leaves no training rows out of %d" % (test_size, len(self)))
+        return slice(0, n_train), slice(n_train, len(self))
+
 
 def encode_columns(cols, shuffle=True, random_state=42) -> EncodedRatings:
     """neural_network.py:41-60: encode both id columns by first appearance, then shuffle the rows

@@ -82,8 +82,18 @@ def _improved(cur, best, mode):
     return cur < best if mode == "min" else cur > best
 
 
+def _column(col, rows, dtype, dev):
+    """rows ``rows`` of a table column (NumPy on the host or a torch tensor already in HBM) as a device tensor"""
+    col = col[rows]
+    if isinstance(col, torch.Tensor):
+        return col.to(device=dev, dtype=dtype).contiguous()
+    np_dtype = {torch.int32: np.int32, torch.float32: np.float32}[dtype]
+    return torch.as_tensor(np.asarray(col, np_dtype), device=dev)
+
+
 def fit(table: RatingTable, cfg: FitConfig, engine=None, log=print, device="cuda:0") -> FitResult:
-    """Train the embedding model on ``table``; returns History + last and best weights."""
+    """Train the embedding model on ``table`` (a ``data.RatingTable`` of NumPy columns or an
+    ``ingest.EncodedRatings`` whose columns already live in HBM); returns History + last and best weights."""
     if cfg.embedding_size != 128:
         raise ValueError("libanirec kernels are specialised for embedding_size 128 (config.yaml:63)")
     tr, te = table.split(cfg.test_size)
@@ -98,12 +108,10 @@ def fit(table: RatingTable, cfg: FitConfig, engine=None, log=print, device="cuda
     engine.set_weights(U0, A0)
     engine.reset_optimizer()
 
-    ui = torch.as_tensor(table.user[tr], device=dev).to(torch.int32)
-    ai = torch.as_tensor(table.anime[tr], device=dev).to(torch.int32)
-    rt = torch.as_tensor(np.asarray(table.rating[tr], np.float32), device=dev)
-    vu = torch.as_tensor(table.user[te], device=dev).to(torch.int32)
-    va = torch.as_tensor(table.anime[te], device=dev).to(torch.int32)
-    vt = torch.as_tensor(np.asarray(table.rating[te], np.float32), device=dev)
+    ui, ai, rt = (_column(c, tr, dt, dev) for c, dt in ((table.user, torch.int32), (table.anime, torch.int32),
+                                                        (table.rating, torch.float32)))
+    vu, va, vt = (_column(c, te, dt, dev) for c, dt in ((table.user, torch.int32), (table.anime, torch.int32),
+                                                        (table.rating, torch.float32)))
 
     B = min(cfg.batch_size, n_train)
     # multi-GPU (dist.DistTrainEngine): each rank takes B ratings of a global batch of G*B

@@ -76,7 +76,12 @@ def go(args):
             per_rank = cfg.batch_size
             cfg.max_lr = cfg.max_lr * world
         else:
-            per_rank = max(1, cfg.batch_size // world)
+            if cfg.batch_size % world:
+                # a remainder would silently shrink the global batch: other steps per epoch, Adam step sizes, History
+                raise ValueError("batch_size %d is not a multiple of the %d ranks: the global batch of model.fit "
+                                 "(neural_network.py:213) must be cut into equal per-rank parts (or set "
+                                 "ANIREC_WEAK_SCALING=1 for batch_size ratings PER rank)" % (cfg.batch_size, world))
+            per_rank = cfg.batch_size // world
         engine = DistTrainEngine(table.n_users, table.n_anime, min(per_rank, max(1, n_train // world)),
                                  l2=cfg.l2_reg_factor, device="cuda:%d" % local)
         if rank != 0:

@@ -7,10 +7,17 @@ and ``bench.py``'s ``cpu_baseline`` leg may import this module; the product
 PARITY PINNING: the reference has no tests and TensorFlow/Keras 2.12 (where the
 arithmetic lives, un-vendored: ``neural_network/conda.yml:20-21``) is not
 installed here, so this restates the *published* Keras 2.12 / NumPy semantics
-at the reference's call sites.  The only numeric known-answer the reference
-holds is the ``lr`` column of ``figure_file/anime_nn_history.csv`` — ``lrfn``
-below is pinned to it (tests/test_oracle.py).  Everything else is
-**parity unpinned** (see DESIGN.md).
+at the reference's call sites.  What IS pinned to the reference itself
+(tests/test_reference_fixtures.py, fixtures generated from the reference's own
+function bodies by tests/golden/make_reference_function_fixtures.py, under
+numpy 2.2 / pandas 2.3 — not the reference's pinned 1.23.5 / 1.5.3):
+``lrfn`` (also the ``lr`` column of ``figure_file/anime_nn_history.csv``),
+``rownorm`` (= get_weights), the cosine neighbour lists of ``find_similar_users``,
+and — in ingest_oracle.py / recs_oracle.py — preprocess, favourites, ``clean`` /
+``by_genre``, ``get_unwatched``.  What stays **parity unpinned**: everything
+that executes inside Keras/TensorFlow — the forward graph, the train step
+(closed-form backward + Adam), validation metrics and ``model.predict`` —
+because nothing in the reference holds a vector for it.
 
 Each function cites the reference file:line it follows.  ``dtype`` selects the
 arithmetic type: ``np.float32`` is the parity oracle (what Keras computes in),

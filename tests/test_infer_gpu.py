@@ -324,7 +324,7 @@ def test_key_range_splits_give_the_same_lists(k, monkeypatch):
     for sp in ("1", "2", "3", "4"):
         monkeypatch.setenv("ANIREC_TOPK_SPLITS", sp)
         idx, sim, nfb = ops.cosine_topk_mfma(Wh, q, k)
-        if sp != "2":                      # two splits of a k = 100 super-step may overflow their 96-entry regions
+        if sp != "2":                      # two splits of a k = 100 super-step may overflow their 88-entry regions
             assert nfb == 0, sp            # (those rows fall back to the exact path: still the same lists)
         if ref is None:
             ref = (idx.clone(), sim.clone())
