@@ -21,6 +21,7 @@ MAX_TOPK = 128
 MAX_SEG = 16
 ABI_VERSION = 3
 TOPK_MAX_BATCHES = 64
+RCCL_ID_BYTES = 128
 
 
 class AnirecError(RuntimeError):
@@ -95,6 +96,11 @@ PROTOTYPES = {
     "anirec_dist_stepper_destroy": (C.c_int, [_vp]),
     "anirec_dist_step_mid": (C.c_int, [_vp, _vp]),
     "anirec_dist_step_back": (C.c_int, [_vp, _vp]),
+    "anirec_rccl_load": (C.c_int, [C.c_char_p]),
+    "anirec_rccl_unique_id": (C.c_int, [C.c_char_p]),
+    "anirec_dist_comm_create": (C.c_int, [C.c_char_p, _i32, _i32, C.POINTER(_vp)]),
+    "anirec_dist_comm_destroy": (C.c_int, [_vp]),
+    "anirec_dist_run": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "anirec_trainer_create": (C.c_int, [_DP, C.POINTER(_vp)]),
     "anirec_trainer_destroy": (C.c_int, [_vp]),
     "anirec_trainer_run": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),

@@ -15,11 +15,13 @@ const char *anirec_status_string(int status) {
     case ANIREC_EINVAL:
       return "invalid argument";
     case ANIREC_ENODEVICE:
-      return "no gfx950 HIP device";
+      return "no gfx950 HIP device (or RCCL not loadable)";
     case ANIREC_EWORKSPACE:
       return "workspace too small";
     case ANIREC_ECAPTURE:
       return "hipGraph capture/instantiate failed";
+    case ANIREC_ECOMM:
+      return "RCCL call failed";
     default:
       break;
   }

@@ -33,7 +33,10 @@
 // bandwidth-saturating stream (270-400 us per step against 232).
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is bound at run time (dlopen), never linked
 #include <stdlib.h>
+#include <string.h>
 
 #include <new>
 
@@ -1635,6 +1638,8 @@ struct anirec_dist_stepper {
   TrainWs ws;
   hipStream_t side;
   hipEvent_t fork, join;
+  hipGraphExec_t exec;  // anirec_dist_run(use_graph): a captured block of steps, collectives included
+  int graph_steps;
 };
 
 int anirec_dist_stepper_create(const anirec_train_desc *d, anirec_dist_stepper **out) {
@@ -1648,6 +1653,8 @@ int anirec_dist_stepper_create(const anirec_train_desc *d, anirec_dist_stepper *
   h->ws = carve(d->workspace, d->max_batch, d->arena_steps);
   h->side = nullptr;
   h->fork = h->join = nullptr;
+  h->exec = nullptr;
+  h->graph_steps = 0;
   if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&h->fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->join, hipEventDisableTiming) != hipSuccess) {
@@ -1660,6 +1667,7 @@ int anirec_dist_stepper_create(const anirec_train_desc *d, anirec_dist_stepper *
 
 int anirec_dist_stepper_destroy(anirec_dist_stepper *h) {
   if (!h) return ANIREC_EINVAL;
+  if (h->exec) (void)hipGraphExecDestroy(h->exec);
   if (h->fork) (void)hipEventDestroy(h->fork);
   if (h->join) (void)hipEventDestroy(h->join);
   if (h->side) (void)hipStreamDestroy(h->side);
@@ -1694,6 +1702,198 @@ int anirec_dist_step_back(anirec_dist_stepper *h, void *stream) {
     return launch_adam_full(&h->d, h->ws, s, 2);
   }
   return launch_adam_full(&h->d, h->ws, s, 0);
+}
+
+// ---- multi-GPU: the whole loop in the library, RCCL called from here -----------------------------------------
+// The step sequence above driven from C: one call enqueues prep + n_steps x {fwd -> all-gather(packets) -> mid ->
+// all-reduce | reduce-scatter(dense grad) -> back [-> all-gather(W rows)]} on the engine's stream, the collectives
+// issued to RCCL on that same stream (no Python, no torch.distributed in the step).  RCCL is bound with dlopen — the
+// copy the process has already loaded (torch's) when there is one — so the library has no link-time dependency on
+// it and a box without RCCL still loads libanirec.
+struct RcclApi {
+  void *lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclReduceScatter) ReduceScatter = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+};
+static RcclApi g_rccl;
+
+static int rccl_bind(void *lib) {
+  RcclApi a;
+  a.lib = lib;
+#define ANIREC_SYM(F)                                               \
+  a.F = reinterpret_cast<decltype(a.F)>(dlsym(lib, "nccl" #F));     \
+  if (!a.F) return ANIREC_ENODEVICE;
+  ANIREC_SYM(GetUniqueId)
+  ANIREC_SYM(CommInitRank)
+  ANIREC_SYM(CommDestroy)
+  ANIREC_SYM(AllGather)
+  ANIREC_SYM(AllReduce)
+  ANIREC_SYM(ReduceScatter)
+  ANIREC_SYM(GroupStart)
+  ANIREC_SYM(GroupEnd)
+#undef ANIREC_SYM
+  g_rccl = a;
+  return ANIREC_OK;
+}
+
+int anirec_rccl_load(const char *path_host) {
+  if (g_rccl.lib) return ANIREC_OK;
+  if (path_host && path_host[0]) {
+    void *l = dlopen(path_host, RTLD_NOW | RTLD_LOCAL);
+    return l ? rccl_bind(l) : ANIREC_ENODEVICE;
+  }
+  static const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (int pass = 0; pass < 2; ++pass)  // first a copy that is already mapped (torch's), then a fresh load
+    for (const char *nm : names) {
+      void *l = dlopen(nm, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+      if (l && rccl_bind(l) == ANIREC_OK) return ANIREC_OK;
+    }
+  return ANIREC_ENODEVICE;
+}
+
+int anirec_rccl_unique_id(char *id_host) {
+  if (!id_host) return ANIREC_EINVAL;
+  if (!g_rccl.lib) return ANIREC_ENODEVICE;
+  ncclUniqueId id;
+  if (g_rccl.GetUniqueId(&id) != ncclSuccess) return ANIREC_ECOMM;
+  static_assert(sizeof(id) == ANIREC_RCCL_ID_BYTES, "ncclUniqueId size");
+  memcpy(id_host, &id, sizeof(id));
+  return ANIREC_OK;
+}
+
+struct anirec_dist_comm {
+  ncclComm_t comm;
+  int rank, world;
+};
+
+int anirec_dist_comm_create(const char *id_host, int32_t rank, int32_t world, anirec_dist_comm **out) {
+  if (!id_host || !out || world < 1 || world > ANIREC_MAX_SEG || rank < 0 || rank >= world) return ANIREC_EINVAL;
+  if (!g_rccl.lib) return ANIREC_ENODEVICE;
+  anirec_dist_comm *c = new (std::nothrow) anirec_dist_comm;
+  if (!c) return ANIREC_EINVAL;
+  ncclUniqueId id;
+  memcpy(&id, id_host, sizeof(id));
+  c->rank = rank;
+  c->world = world;
+  if (g_rccl.CommInitRank(&c->comm, world, id, rank) != ncclSuccess) {  // collective: every rank calls it
+    delete c;
+    return ANIREC_ECOMM;
+  }
+  *out = c;
+  return ANIREC_OK;
+}
+
+int anirec_dist_comm_destroy(anirec_dist_comm *c) {
+  if (!c) return ANIREC_EINVAL;
+  if (g_rccl.lib) (void)g_rccl.CommDestroy(c->comm);
+  delete c;
+  return ANIREC_OK;
+}
+
+#define ANIREC_RCCL_CHECK(expr)                      \
+  do {                                               \
+    if ((expr) != ncclSuccess) return ANIREC_ECOMM;  \
+  } while (0)
+
+// reduce-scatter form of the replicated tables: this rank's Adam only updates its row shard
+static inline bool row_sharded(const anirec_train_desc *d) {
+  return d->dense_mode == 2 && (d->adam_row_lo | d->adam_row_hi) != 0;
+}
+
+static int dist_one_step(anirec_dist_stepper *h, anirec_dist_comm *c, hipStream_t s) {
+  const anirec_train_desc *d = &h->d;
+  int e;
+  if ((e = launch_fwd(d, h->ws, s))) return e;
+  // BatchNorm sees the global batch: every rank's (c, t, count, mean, M2) packet, gathered in place
+  const size_t pf = anirec_packet_floats(d->max_batch);
+  ANIREC_RCCL_CHECK(g_rccl.AllGather(d->packets + pf * (size_t)c->rank, d->packets, pf, ncclFloat, c->comm, s));
+  if ((e = anirec_dist_step_mid(h, s))) return e;
+  float *g = d->dense_grad;
+  const size_t nd = (size_t)d->dense_rows;
+  if (row_sharded(d)) {
+    // rows and self-coefficient sums of this rank's shard only, in place (dense_rows is a multiple of the world size)
+    const size_t sr = nd / (size_t)c->world;
+    ANIREC_RCCL_CHECK(g_rccl.GroupStart());
+    ANIREC_RCCL_CHECK(g_rccl.ReduceScatter(g, g + (size_t)c->rank * sr * kDim, sr * kDim, ncclFloat, ncclSum, c->comm, s));
+    ANIREC_RCCL_CHECK(g_rccl.ReduceScatter(g + nd * kDim, g + nd * kDim + (size_t)c->rank * sr, sr, ncclFloat, ncclSum,
+                                           c->comm, s));
+    ANIREC_RCCL_CHECK(g_rccl.GroupEnd());
+  } else {
+    ANIREC_RCCL_CHECK(g_rccl.AllReduce(g, g, nd * (kDim + 1), ncclFloat, ncclSum, c->comm, s));
+  }
+  if ((e = anirec_dist_step_back(h, s))) return e;
+  if (row_sharded(d)) {  // every rank updated its row shard: collect the updated rows of W (padded to whole shards)
+    const size_t sr = nd / (size_t)c->world;
+    ANIREC_RCCL_CHECK(g_rccl.AllGather(d->W + (size_t)c->rank * sr * kDim, d->W, sr * kDim, ncclFloat, c->comm, s));
+  }
+  return ANIREC_OK;
+}
+
+// use_graph: blocks of G = min(32, arena_steps / 2) steps — their RCCL collectives and the side-stream fork / join
+// included — are captured once and replayed, the first node of a replay preparing the G steps after it (as the
+// one-GPU trainer does); every rank replays in lockstep.  If the capture or the instantiation fails the loop falls
+// back to eager launches for good (decided before anything of the block has been enqueued).
+int anirec_dist_run(anirec_dist_stepper *h, anirec_dist_comm *c, int32_t first_step, int32_t n_steps, int32_t use_graph,
+                    void *stream) {
+  if (!h || !c || n_steps < 0 || first_step < 0 || first_step + n_steps > h->d.n_steps) return ANIREC_EINVAL;
+  if (!g_rccl.lib) return ANIREC_ENODEVICE;
+  if (c->world != h->d.n_seg || c->rank != h->d.my_seg) return ANIREC_EINVAL;
+  if (!h->d.user_idx || !h->d.anime_idx || !h->d.rating || !h->d.sched || !h->d.dense_grad) return ANIREC_EINVAL;
+  if (row_sharded(&h->d) && h->d.dense_rows % c->world) return ANIREC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  int G = h->d.arena_steps / 2;
+  if (G > 32) G = 32;
+  int done = 0;
+  bool graph = use_graph && s != nullptr && G >= 4 && n_steps >= G && !g_ticks_on && h->graph_steps >= 0;
+  if (graph && !h->exec) {
+    hipGraph_t g = nullptr;
+    int e = ANIREC_ECAPTURE;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
+      e = launch_prep(&h->d, h->ws, G, G, true, s);  // steps cursor+G .. cursor+2G
+      for (int i = 0; i < G && !e; ++i) e = dist_one_step(h, c, s);
+      if (hipStreamEndCapture(s, &g) != hipSuccess || !g) e = e ? e : ANIREC_ECAPTURE;
+    }
+    if (!e && hipGraphInstantiate(&h->exec, g, nullptr, nullptr, 0) != hipSuccess) {
+      h->exec = nullptr;
+      e = ANIREC_ECAPTURE;
+    }
+    if (g) (void)hipGraphDestroy(g);
+    if (e) {
+      (void)hipGetLastError();
+      h->graph_steps = -1;  // never again: eager from here on
+      graph = false;
+    } else {
+      h->graph_steps = G;
+    }
+  }
+  if (graph) {
+    int e = launch_prep(&h->d, h->ws, first_step, G, false, s);  // the first block; later ones by the graph
+    if (e) return e;
+    while (n_steps - done >= G) {
+      ANIREC_HIP_CHECK(hipGraphLaunch(h->exec, s));
+      done += G;
+    }
+  }
+  while (done < n_steps) {
+    int blk = n_steps - done;
+    if (!(graph && done > 0)) {  // no replay before: prepare arena-sized blocks from the host
+      if (blk > h->d.arena_steps) blk = h->d.arena_steps;
+      int e = launch_prep(&h->d, h->ws, first_step + done, blk, false, s);
+      if (e) return e;
+    }
+    for (int i = 0; i < blk; ++i) {
+      int e = dist_one_step(h, c, s);
+      if (e) return e;
+    }
+    done += blk;
+  }
+  return ANIREC_OK;
 }
 
 // ---- one GPU: the whole loop ------------------------------------------------------------------------------

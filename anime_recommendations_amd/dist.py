@@ -28,10 +28,16 @@ In every mode BatchNorm couples the global batch: one all-gather of the 8-byte-p
 (c, t) per step lets every rank redo the cheap scalar head over the whole batch, so the result equals a
 single-GPU step on the global batch (not per-replica BN).
 
-Per step Python issues three C calls and the collectives between them:
+The step:
     step_front (fwd)  ->  all_gather(packets)  ->  step_mid (head, bwd, densify [+ user-row adam forked onto
     a side stream])  ->  all_reduce / reduce_scatter(dense grad)  ->  step_back (adam of the rows that needed
     the collective + step finish)  [->  all_gather(W) in replicated_rs].
+Backend "nccl": the whole loop runs INSIDE libanirec (``anirec_dist_run``: one C call per run(), the collectives issued
+to RCCL from C on the engine's stream through the library's own communicator, bootstrapped with a unique id that
+torch.distributed broadcasts once).  Any other backend (gloo: CPU / one-GPU rehearsal) keeps the loop in Python with
+torch.distributed collectives — three C calls and two or three collectives per step.  The path is chosen ONCE, at
+construction, from ``dist.get_backend()`` (RCCL reports errors asynchronously: a try/except around a collective cannot
+be the thing that saves a step).
 """
 from __future__ import annotations
 
@@ -139,13 +145,56 @@ class DistTrainEngine:
         self.cursor = 0
         pf = self.eng.packet_floats
         self._send = torch.zeros(pf, dtype=torch.float32, device=self.device)
-        self._use_flat_gather = True
-        self._use_reduce_scatter = True
+        # collective variants of the PYTHON loop, decided once from the backend: RCCL has the flat-tensor forms and
+        # reduce-scatter; gloo has neither (list all-gather, and the shard sums by all-reduce)
+        backend = dist.get_backend()
+        self._use_flat_gather = backend == "nccl"
+        self._use_reduce_scatter = backend == "nccl"
+        self._comm = None
+        if loop and backend == "nccl" and os.environ.get("ANIREC_DIST_NATIVE", "1") != "0":
+            self._comm = self._native_comm()
         if self.mode == "replicated_rs":
             sr = self.shard_rows
             self._rs_g = torch.zeros(sr * _lib.DIM, dtype=torch.float32, device=self.device)
             self._rs_s = torch.zeros(sr, dtype=torch.float32, device=self.device)
             self._ag_w = torch.zeros(sr, _lib.DIM, dtype=torch.float32, device=self.device)
+
+    def _native_comm(self):
+        """The library's own RCCL communicator over the same ranks (collective).  Every rank must take the same
+        decision: the outcome of loading RCCL is agreed with one MIN all-reduce before anyone creates a communicator."""
+        import ctypes as C
+        import sys
+        lib = self.eng.lib
+        ok = int(lib.anirec_rccl_load(None) == 0)
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            return None
+        # RCCL prints a version banner on STDOUT when it is initialised outside torch: keep stdout clean (bench.py's
+        # contract is ONE JSON line there) by pointing fd 1 at stderr while the id and the communicator are made
+        sys.stdout.flush()
+        saved = os.dup(1)
+        h = C.c_void_p()
+        try:
+            os.dup2(2, 1)
+            idb = C.create_string_buffer(_lib.RCCL_ID_BYTES)
+            rc = lib.anirec_rccl_unique_id(idb) if self.rank == 0 else 0
+            t = torch.frombuffer(bytearray(idb.raw), dtype=torch.uint8).to(self.device)
+            dist.broadcast(t, src=0)                      # (also when rank 0 failed: nobody is left in a collective)
+            raw = bytes(t.cpu().numpy().tobytes())
+            if rc == 0:
+                with torch.cuda.device(self.device):
+                    rc = lib.anirec_dist_comm_create(raw, self.rank, self.world, C.byref(h))
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        _lib.check(rc, "anirec_rccl_unique_id / anirec_dist_comm_create")
+        return h
+
+    @property
+    def native(self):
+        """True when run() is one C call with RCCL inside (backend nccl), False for the Python step loop."""
+        return self._comm is not None
 
     # ---- weights ---------------------------------------------------------------------------
     def set_head(self, **kw):
@@ -229,12 +278,9 @@ class DistTrainEngine:
         pf = e.packet_floats
         self._send.copy_(e.packets[self.rank * pf:(self.rank + 1) * pf])
         if self._use_flat_gather:
-            try:
-                dist.all_gather_into_tensor(e.packets, self._send)
-                return
-            except (RuntimeError, NotImplementedError):
-                self._use_flat_gather = False
-        dist.all_gather([e.packets[r * pf:(r + 1) * pf] for r in range(self.world)], self._send)
+            dist.all_gather_into_tensor(e.packets, self._send)
+        else:
+            dist.all_gather([e.packets[r * pf:(r + 1) * pf] for r in range(self.world)], self._send)
 
     def _reduce_dense(self):
         """Sum the dense gradient buffer over the ranks (RCCL over xGMI): all-reduce, or — replicated_rs —
@@ -246,16 +292,13 @@ class DistTrainEngine:
             return
         nd, sr = e.dense_rows, self.shard_rows
         if self._use_reduce_scatter:
-            try:
-                dist.reduce_scatter_tensor(self._rs_g, g[: nd * _lib.DIM])
-                dist.reduce_scatter_tensor(self._rs_s, g[nd * _lib.DIM:])
-                lo = self.rank * sr
-                g[lo * _lib.DIM:(lo + sr) * _lib.DIM].copy_(self._rs_g)
-                g[nd * _lib.DIM + lo: nd * _lib.DIM + lo + sr].copy_(self._rs_s)
-                return
-            except (RuntimeError, NotImplementedError):     # gloo has no reduce-scatter: same sums by all-reduce
-                self._use_reduce_scatter = False
-        dist.all_reduce(g)
+            dist.reduce_scatter_tensor(self._rs_g, g[: nd * _lib.DIM])
+            dist.reduce_scatter_tensor(self._rs_s, g[nd * _lib.DIM:])
+            lo = self.rank * sr
+            g[lo * _lib.DIM:(lo + sr) * _lib.DIM].copy_(self._rs_g)
+            g[nd * _lib.DIM + lo: nd * _lib.DIM + lo + sr].copy_(self._rs_s)
+        else:                                               # gloo has no reduce-scatter: the same sums by all-reduce
+            dist.all_reduce(g)
 
     def _all_gather_rows(self):
         """replicated_rs: every rank updated its row shard; collect the updated rows of W."""
@@ -264,12 +307,9 @@ class DistTrainEngine:
         lo = self.rank * sr
         self._ag_w.copy_(e._Wfull[lo:lo + sr])
         if self._use_flat_gather:
-            try:
-                dist.all_gather_into_tensor(e._Wfull, self._ag_w)
-                return
-            except (RuntimeError, NotImplementedError):
-                self._use_flat_gather = False
-        dist.all_gather([e._Wfull[r * sr:(r + 1) * sr] for r in range(self.world)], self._ag_w)
+            dist.all_gather_into_tensor(e._Wfull, self._ag_w)
+        else:
+            dist.all_gather([e._Wfull[r * sr:(r + 1) * sr] for r in range(self.world)], self._ag_w)
 
     def step(self):
         """One optimiser step of the multi-GPU loop: 3 C calls + 2 (3) collectives."""
@@ -290,6 +330,14 @@ class DistTrainEngine:
             n_steps = e.n_steps - first_step
         if not self.loop:
             e.run(n_steps, use_graph=use_graph, first_step=first_step)
+            self.cursor = first_step + n_steps
+            return n_steps
+        if self._comm is not None:              # the whole loop in the library, RCCL called from C
+            # ANIREC_DIST_GRAPH=1: replay captured blocks of steps (RCCL inside the hipGraph; rehearsed with one rank,
+            # never yet run on several GPUs: opt-in)
+            graph = int(bool(use_graph) and os.environ.get("ANIREC_DIST_GRAPH", "0") == "1")
+            _lib.check(e.lib.anirec_dist_run(e._get_stepper(), self._comm, int(first_step), int(n_steps), graph,
+                                             e._sp()), "anirec_dist_run")
             self.cursor = first_step + n_steps
             return n_steps
         done = 0
@@ -348,6 +396,10 @@ class DistTrainEngine:
         self.eng.synchronize()
 
     def close(self):
+        if self._comm is not None:
+            self.eng.synchronize()
+            self.eng.lib.anirec_dist_comm_destroy(self._comm)
+            self._comm = None
         self.eng.close()
 
 

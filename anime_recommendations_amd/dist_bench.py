@@ -8,8 +8,9 @@ the parent then starts its N ranks itself as child processes — before it has m
 The headline number is the user-sharded mode (dist.py).  After it, on the same ranks and the same synthetic
 ratings, the two replicated-table modes are timed for a few steps (``also.dp_modes``): the literal
 "replicated variables + dense all-reduce of both tables" baseline of the reference's TPU branch
-(neural_network.py:173-178) and its reduce-scatter -> shard-Adam -> all-gather form.  A watchdog prints the
-headline line without them if that leg stalls, so the extras can never cost the scaling number.
+(neural_network.py:173-178) and its reduce-scatter -> shard-Adam -> all-gather form.  The ONE JSON line is printed at
+the end; if the extras stall, a watchdog prints it without them (``also.extras_error``) and the process exits with
+status 3, so the scaling number survives and the driver still sees that something went wrong.
 """
 from __future__ import annotations
 
@@ -180,6 +181,7 @@ def _train_leg(mode, data, tables, n_users, n_anime, B, K, W, inst, rank, world,
            "host_issue_ms_per_step": t_issue / K * 1e3,
            # share of the step the host needs just to enqueue it: near 1.0 the Python loop, not the GPU, sets the pace
            "host_bound_frac": min(1.0, t_issue / dt), "stage_ms": kern_ms,
+           "loop": "native (anirec_dist_run: RCCL from C)" if eng.native else "python (torch.distributed collectives)",
            "final_loss": float(rec["last_loss"]), "local_rows": int(e.rows),
            "adam_rows": int(e.adam_rows[1] - e.adam_rows[0]) if (e.adam_rows[0] | e.adam_rows[1]) else int(e.rows),
            "dense_grad_bytes": int(e.dense_grad.numel() * 4) if e.dense_grad is not None else 0}
@@ -228,6 +230,7 @@ def _run(args, rank, world, dev):
                      "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms": head["ms_per_step"]},
         "cpu_baseline": None,
         "host_issue_ms_per_step": head["host_issue_ms_per_step"], "host_bound_frac": head["host_bound_frac"],
+        "step_loop": head["loop"],
         "kernels_ms": head["stage_ms"],
         "final_loss": head["final_loss"],
         "also": {},
@@ -241,11 +244,12 @@ def _run(args, rank, world, dev):
             print(json.dumps(line), flush=True)
 
     # the extras below involve collectives of their own: if any rank stalls in them, every rank gives up after the
-    # timeout, rank 0 having printed the headline line (os._exit: the other ranks may sit in a collective)
+    # timeout: rank 0 prints the headline line with the error recorded, and every rank exits NON-ZERO (os._exit: the
+    # other ranks may sit in a collective) so that the stall is visible to whoever launched the bench
     def give_up():
         line["also"]["extras_error"] = "timed out after %s s" % timeout_s
         emit()
-        os._exit(0)
+        os._exit(3)
 
     timeout_s = float(os.environ.get("ANIREC_BENCH_EXTRAS_TIMEOUT", "300"))
     dog = None

@@ -44,7 +44,8 @@ enum {
   ANIREC_EINVAL = -1,     /* bad argument (null pointer, size out of range, dim != 128) */
   ANIREC_ENODEVICE = -2,  /* no HIP device / wrong architecture */
   ANIREC_EWORKSPACE = -3, /* workspace too small */
-  ANIREC_ECAPTURE = -4    /* graph capture / instantiate failed */
+  ANIREC_ECAPTURE = -4,   /* graph capture / instantiate failed */
+  ANIREC_ECOMM = -5       /* an RCCL call failed */
 };
 
 int anirec_abi_version(void);
@@ -184,6 +185,27 @@ int anirec_dist_stepper_create(const anirec_train_desc *d, anirec_dist_stepper *
 int anirec_dist_stepper_destroy(anirec_dist_stepper *h);
 int anirec_dist_step_mid(anirec_dist_stepper *h, void *stream);
 int anirec_dist_step_back(anirec_dist_stepper *h, void *stream);
+
+/* The same loop inside the library, the collectives issued to RCCL from C on the engine's stream (one call per
+ * block of steps instead of three C calls and two torch.distributed calls per step).  Replaces the reference's only
+ * data-parallel construct, neural_network/neural_network.py:142-147,173-178 (replicated variables under a strategy
+ * scope: a dense gradient all-reduce per step).  RCCL is bound at run time: anirec_rccl_load(NULL) takes the copy the
+ * process has mapped already (torch's) or loads librccl.so.1; ANIREC_ENODEVICE if there is none.
+ *   rank 0: anirec_rccl_unique_id(id) -> the caller broadcasts the ANIREC_RCCL_ID_BYTES bytes -> every rank:
+ *   anirec_dist_comm_create(id, rank, world) (collective; the current HIP device) -> anirec_dist_run(...) per epoch. */
+#define ANIREC_RCCL_ID_BYTES 128
+int anirec_rccl_load(const char *path_host);
+int anirec_rccl_unique_id(char *id_host);
+typedef struct anirec_dist_comm anirec_dist_comm;
+int anirec_dist_comm_create(const char *id_host, int32_t rank, int32_t world, anirec_dist_comm **out_host);
+int anirec_dist_comm_destroy(anirec_dist_comm *c);
+/* steps [first_step, first_step + n_steps) of the stepper's descriptor (n_seg = world, my_seg = rank); the packet
+ * all-gather, the gradient all-reduce / reduce-scatter and the W all-gather run in place on the descriptor's buffers.
+ * first_step must equal the device cursor.  use_graph != 0: blocks of min(32, arena_steps/2) steps, collectives
+ * included, are captured once and replayed (every rank must pass the same value); a failed capture falls back to
+ * eager launches. */
+int anirec_dist_run(anirec_dist_stepper *h, anirec_dist_comm *c, int32_t first_step, int32_t n_steps, int32_t use_graph,
+                    void *stream);
 
 /* Steps [first_step, first_step + n_steps) — prep, fwd, head, bwd, adam — on one GPU; first_step
  * must equal the device cursor state->step_fwd.  use_graph != 0 replays a captured hipGraph of

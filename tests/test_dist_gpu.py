@@ -106,14 +106,15 @@ def test_two_ranks_on_one_gpu_match_oracle_on_global_batches(tmp_path, mode):
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: two GPUs")
-@pytest.mark.parametrize("mode", ["sharded", "replicated_rs"])
+@pytest.mark.parametrize("mode", ["sharded", "replicated", "replicated_rs"])
 def test_two_ranks_on_two_gpus_over_rccl_match_oracle(tmp_path, mode):
     mp.spawn(_worker, args=(2, _port(), str(tmp_path), mode, "nccl"), nprocs=2, join=True)
     _check_against_oracle(tmp_path)
 
 
 def _nccl_world1_worker(rank, port, out_dir):
-    """The N>1 step loop under the backend it ships with: RCCL, one rank, ANIREC_DIST_LOOP=1."""
+    """The N>1 step loop under the backend it ships with: RCCL, one rank, ANIREC_DIST_LOOP=1 — the collectives really
+    execute (in place, on the engine's stream), from C and from torch.distributed."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
                       ANIREC_DIST_LOOP="1")
     dev = torch.device("cuda:0")
@@ -138,9 +139,15 @@ def _nccl_world1_worker(rank, port, out_dir):
         ref.run(n_steps, use_graph=False)
         rref = ref.read_state()
         out = {}
-        for mode in ("sharded", "replicated", "replicated_rs"):
-            eng = DistTrainEngine(U.shape[0], A.shape[0], B, l2=1e-4, arena_steps=4, device=dev, mode=mode)
+        # both forms of the loop: inside the library with RCCL called from C (the shipping path under backend nccl),
+        # and in Python with torch.distributed collectives (ANIREC_DIST_NATIVE=0)
+        for mode, native in [(m, nv) for m in ("sharded", "replicated", "replicated_rs") for nv in ("1", "graph", "0")]:
+            os.environ["ANIREC_DIST_NATIVE"] = "0" if native == "0" else "1"
+            os.environ["ANIREC_DIST_GRAPH"] = "1" if native == "graph" else "0"
+            # (arena of 8: the graph variant replays one captured block of 4 steps, then runs the ragged fifth eagerly)
+            eng = DistTrainEngine(U.shape[0], A.shape[0], B, l2=1e-4, arena_steps=8, device=dev, mode=mode)
             assert eng.loop and eng.eng.dense_mode == (1 if mode == "sharded" else 2)
+            assert eng.native == (native != "0"), (mode, native)
             eng.set_head(w=1.2)
             eng.set_weights(U, A)
             eng.set_epoch_global(tu, ta, tt, tp, alphas)
@@ -154,7 +161,7 @@ def _nccl_world1_worker(rank, port, out_dir):
             for k in ("w", "b", "gamma", "beta", "mov_mean", "mov_var"):
                 assert rec[k] == rref[k], (mode, k)
             assert abs(float(rec["last_loss"]) - float(rref["last_loss"])) < 2e-6
-            out[mode] = eng.epoch_metrics()[0]
+            out[mode + native] = eng.epoch_metrics()[0]
             eng.close()
         assert max(out.values()) - min(out.values()) < 2e-6
         ref.close()
