@@ -179,9 +179,13 @@ class DistTrainEngine:
             os.dup2(2, 1)
             idb = C.create_string_buffer(_lib.RCCL_ID_BYTES)
             rc = lib.anirec_rccl_unique_id(idb) if self.rank == 0 else 0
-            t = torch.frombuffer(bytearray(idb.raw), dtype=torch.uint8).to(self.device)
-            dist.broadcast(t, src=0)                      # (also when rank 0 failed: nobody is left in a collective)
-            raw = bytes(t.cpu().numpy().tobytes())
+            # the id + rank 0's status in one broadcast: if rank 0 failed, EVERY rank raises, nobody is left in a collective
+            t = torch.frombuffer(bytearray(idb.raw) + bytearray([1 if rc == 0 else 0]), dtype=torch.uint8).to(self.device)
+            dist.broadcast(t, src=0)
+            got = t.cpu().numpy().tobytes()
+            raw = got[:_lib.RCCL_ID_BYTES]
+            if rc == 0 and got[-1] != 1:
+                rc = -5                                      # ANIREC_ECOMM: rank 0 could not make the id
             if rc == 0:
                 with torch.cuda.device(self.device):
                     rc = lib.anirec_dist_comm_create(raw, self.rank, self.world, C.byref(h))
