@@ -655,6 +655,16 @@ constexpr int kMaxSurv = 256;
 // sign * c, so every key that is not a survivor has rating <= rating(tau - eps): the row is complete iff
 // k survivors lie strictly above that bound (a few ulps of slack for the fast exp); saturated heads and
 // worst-case MFMA errors fail the test and fall back to the exact path.
+//
+// Measured in round 3 (rocprofv3, 350 k keys x 65 536 queries): at k = 100 the kernel re-reads ~110 fp32 rows of
+// 512 B per query — 56 KB per query, 3.7 GB per 65 536 queries, 19.7 GB for the all-pairs job — and runs at
+// 6.4-6.9 TB/s of that gather (580 us per 65 536 queries): it is bound by the HBM row gather the EXACT scores need
+// (the key table does not stay in the Infinity Cache between two uses of a row), not by its instructions.  A rewrite
+// with the survivor rows fetched coalesced into a 16-row LDS tile one tile ahead, the chain walked from LDS and a
+// bitonic sort of 64-bit {score, index} keys in place of the O(survivors^2) rank reached 537 us (-7 %) at k = 100 and
+// was 1.6-2.5x SLOWER at k = 10 (a dozen survivors: the sort's 21 dependent cross-lane stages and the tile's LDS
+// footprint cost more than the old rank loop); removing its fetch, its chain or its sort one at a time changed nothing
+// (533-548 us).  Dropped: the bytes are the floor.
 template <bool kPredict>
 __device__ __forceinline__ void rerank_one(const RerankArgs &a, int row, int lane, float *qs, int32_t *sidx, float *sval) {
   const size_t base = (size_t)row * kCap;
@@ -878,6 +888,12 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
   int first = (4 * ca.k_eff + kBN - 1) / kBN;
   if (first > (kCap - kBN) / kBN) first = (kCap - kBN) / kBN;
   if (first < 1) first = 1;
+  // Rows that start from a prior append next to nothing in the first tiles (a prior near the final threshold passes
+  // ~k keys of the WHOLE stream), and their own threshold only overtakes the prior once about half the keys have been
+  // seen: the tiny first super-steps and their refreshes buy nothing, so the first one takes a share of the stream.
+  const char *fpp = getenv("ANIREC_TOPK_FIRST_PRIOR_PCT");
+  const int first_pct = fpp ? atoi(fpp) : 0;
+  if (has_prior && first_pct > 0 && (long long)ntiles * first_pct / 100 > first) first = (int)((long long)ntiles * first_pct / 100);
   // Few queries: fewer workgroups than the chip holds.  From the second super-step on the key tiles of a super-
   // step are then split over up to kMaxSplit workgroups per row block (the first one, with no threshold yet,
   // needs the whole buffer of a row).
@@ -908,7 +924,7 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
     const int t1 = t0 + step < ntiles ? t0 + step : ntiles;
     ca.tile0 = t0;
     ca.tile1 = t1;
-    int splits = t0 == 0 ? 1 : max_split;
+    int splits = (t0 == 0 && !(has_prior && first_pct > 0)) ? 1 : max_split;
     while (splits > 1 && (t1 - t0) < 2 * splits) --splits;  // at least two tiles per workgroup
     if (splits > 1 && splits < min_split) splits = 1;
     ca.splits = splits;
