@@ -1207,6 +1207,11 @@ int anirec_cosine_topk_mfma_prior(const float *What, int32_t n, const int32_t *q
 // MFMA loop is pipe- / power-bound, not latency-bound.  Longer super-steps for rows that start from a prior
 // (ANIREC_TOPK_GROWTH_PRIOR 150-1000 %) cost 10-15 % (38-40 ms against 34.8 on that box), shorter ones (35-70 %)
 // 3-8 %: a row's own threshold, refreshed at every doubling, is worth more than the launches it costs.
+// Last, the re-rank of batch i taken OUT of its chain — a low-priority stream, grid bounded to 2 / 4 / 8 / 16 / 64
+// waves per CU, beside the key stream of batch i + 1 (two sets of buffers): 39-44 ms against 33.0 — the re-rank's
+// 3.7 GB of random row gathers per 65 536 queries push the fp16 key table (90 MB, re-streamed by every k_cand
+// workgroup) out of L2 / Infinity Cache, and k_cand pays for every tile with an HBM round trip.  The side kernels
+// stay where they are: in their chain, alone on the chip.
 constexpr int kMaxLanes = 4;
 struct LanePool {
   int device = -1;
