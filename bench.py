@@ -209,7 +209,7 @@ def cpu_baseline_port(n_users, n_anime, batch, budget_s=12.0):
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense bf16/f16 MFMA peak (MI355X_MICROARCH.md)
 
 
-PMC_ROUND = "r02"
+PMC_ROUND = "r03"
 
 
 def git_blob_hash(path):
@@ -222,13 +222,14 @@ def git_blob_hash(path):
 def pmc_traffic(name, kernels=None, source=None, calls=None):
     """HBM bytes from the committed PMC passes (profiles/<round>_pmc_traffic_<name>.json): per-launch mean of one
     kernel, or the sum over the listed kernels of (mean bytes x launches per call).  The JSON records the git blob
-    hash of every csrc/*.hip at collection time; if `source` (the file holding the kernel) has changed since, the
-    counters no longer describe the kernel being timed and None is returned."""
+    hash of every csrc/*.hip and of the host modules that shape the launches (ops.py ...) at collection time; if any
+    file in `source` has changed since, the counters no longer describe what is being timed and None is returned."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (PMC_ROUND, name))))
-        if source is not None:
-            cur = git_blob_hash(os.path.join(ROOT, "anime_recommendations_amd", "csrc", source))
-            if rec.get("sources", {}).get(source) != cur:
+        for src in ([source] if isinstance(source, str) else (source or [])):
+            sub = "csrc" if src.endswith((".hip", ".hpp")) else ""
+            cur = git_blob_hash(os.path.join(ROOT, "anime_recommendations_amd", sub, src))
+            if rec.get("sources", {}).get(src) != cur:
                 return None
         d = rec["kernels"]
         if isinstance(kernels, str):
@@ -251,28 +252,34 @@ def _cosine_leg(W, nq, k, cpu_baseline, reps=3, slice_note=None, traffic_name=No
     ops.cosine_topk_mfma(Wh, q, k)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    stats = {}
     for _ in range(reps):
         Wh = ops.rownorm(W)
-        idx, sim, nfb = ops.cosine_topk_mfma(Wh, q, k)
+        idx, sim, nfb = ops.cosine_topk_mfma(Wh, q, k, stats=stats)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     flops = 2.0 * nq * n * 128
     # roofline leg: HIP events around the k_cand launches (on the stream they run on) of one extra call of the whole
-    # op — every query batch, with the threshold prior the later batches get from the first one
+    # op — every query batch, with the threshold prior the later batches get from the first one; the timed call runs
+    # its batches on ONE chain so that every timed launch has the chip to itself (the pipeline above runs two)
     acc = {}
     ops.cosine_topk_mfma(Wh, q, k, cand_timing=acc)
     cand_ms, cand_launches = acc.get("ms", 0.0), acc.get("launches", 0)
     tfk = flops / (cand_ms * 1e-3) / 1e12
-    # HBM bytes of all k_cand launches of ONE call of the profiled run (scripts/time_topk.py makes 3 calls; the
-    # 350 k-key profiles are a 65 536-query slice), scaled to this leg's query count
+    # HBM bytes of all k_cand launches of ONE call of the profiled run (scripts/time_topk.py makes 3 calls of the same
+    # job: n keys, nq queries, k)
     traffic = None
-    if traffic_name:
-        for kern in ("k_cand<0, 8, false>", "k_cand<0, 4, false>"):   # 256- or 128-row workgroups (chosen by nq)
-            traffic = traffic or pmc_traffic(traffic_name[0], [kern], source="anirec_topk_mfma.hip", calls=3)
-    if traffic is not None:
-        traffic *= nq / float(traffic_name[1])
+    if traffic_name:       # both instantiations (256- / 128-row workgroups: the learning batch and small jobs use the latter)
+        parts = [pmc_traffic(traffic_name[0], [kern], source=["anirec_topk_mfma.hip", "ops.py"], calls=3)
+                 for kern in ("k_cand<0, 8, false>", "k_cand<0, 4, false>")]
+        if any(p is not None for p in parts):
+            traffic = sum(p for p in parts if p is not None)
+    if traffic is not None and nq != traffic_name[1]:
+        traffic = None      # only a profile of THIS job size is quoted (no scaling of a slice)
     rec = {"value": nq / dt, "unit": "queries/s", "ms": dt * 1e3, "k": k, "n_keys": n, "n_queries": nq,
-           "fallback_rows": int(nfb), "pipeline_tflops": flops / dt / 1e12,
+           "fallback_rows": int(nfb), "rerun_rows": int(stats.get("rerun_rows", 0)),
+           "batches": int(stats.get("batches", 0)), "learn_batches": int(stats.get("learn_batches", 0)),
+           "chains": int(stats.get("lanes", 1)), "pipeline_tflops": flops / dt / 1e12,
            "roofline": {"kernel": "k_cand (v_mfma_f32_16x16x32_f16 scores + fused candidate filter), "
                                   "%d launches summed" % cand_launches,
                         "bound": "mfma", "achieved": tfk, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -307,10 +314,10 @@ def run_cosine_topk(cpu_baseline=True, trained=None):
     out["anime_18k_allpairs_top100"] = _cosine_leg(Wa, 18_000, 100, cpu_baseline,
                                                    traffic_name=("cosine_topk_18k_k100", 18_000))
     out["users_350k_allpairs_top100"] = _cosine_leg(Wu, 350_000, 100, cpu_baseline, reps=2,
-                                                    traffic_name=("cosine_topk_k100", 65_536))
+                                                    traffic_name=("cosine_topk_allpairs_k100", 350_000))
     out["anime_18k_allpairs_top10"] = _cosine_leg(Wa, 18_000, 10, False)
     out["users_350k_allpairs_top10"] = _cosine_leg(Wu, 350_000, 10, False, reps=2,
-                                                   traffic_name=("cosine_topk_k10", 65_536))
+                                                   traffic_name=("cosine_topk_allpairs_k10", 350_000))
     out["users_350k_keys_65536q_top100"] = _cosine_leg(Wu, 65_536, 100, False, traffic_name=("cosine_topk_k100", 65_536),
                                                        slice_note="one 65 536-query slice of the all-pairs job")
     del Wu, Wa

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   scripts/collect_profiles.sh r02 train topk100 topk10 pgrid ptk ingest recs
+#   scripts/collect_profiles.sh r03 train train7m topkall topkall10 topk100 topk18k pgrid ptk ingest recs
 # For each workload: one `--kernel-trace --stats` run, then two SEPARATE `--pmc` runs (FETCH_SIZE, WRITE_SIZE:
 # never combined with each other or with other trace domains).  Output: gpurun_out/<round>/<workload>_{stats,fetch,write}/.
 # scripts/summarise_profiles.py turns them into profiles/<round>_*.
@@ -17,6 +17,7 @@ for W in "$@"; do
     topk100) CMD="$ROOT/scripts/time_topk.py 350000 65536 100";;
     topk10)  CMD="$ROOT/scripts/time_topk.py 350000 65536 10";;
     topkall) CMD="$ROOT/scripts/time_topk.py 350000 350000 100";;
+    topkall10) CMD="$ROOT/scripts/time_topk.py 350000 350000 10";;
     topk18k) CMD="$ROOT/scripts/time_topk.py 18000 18000 100";;
     pgrid)   CMD="$ROOT/scripts/time_predict.py 100000 1 v2";;
     ptk)     CMD="$ROOT/scripts/time_predict_topk.py";;

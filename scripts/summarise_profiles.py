@@ -10,10 +10,11 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd, works = sys.argv[1], sys.argv[2:]
 NAMES = {"train": "train_s109m", "train7m": "train_s7m", "topk100": "cosine_topk_k100", "topk10": "cosine_topk_k10", "topkall": "cosine_topk_allpairs_k100",
+         "topkall10": "cosine_topk_allpairs_k10",
          "topk18k": "cosine_topk_18k_k100", "pgrid": "pgrid", "ptk": "ptk", "ingest": "ingest", "recs": "recs"}
 
 
-NCALLS = {"topk100": 3, "topk10": 3, "topkall": 3, "topk18k": 3, "pgrid": 2, "ptk": 2, "ingest": 3}   # op calls per script run
+NCALLS = {"topk100": 3, "topk10": 3, "topkall": 3, "topkall10": 3, "topk18k": 3, "pgrid": 2, "ptk": 2, "ingest": 3}   # op calls per script run
 
 
 def blob(path):        # `git hash-object`
@@ -26,6 +27,9 @@ def short(n):
 
 
 sources = {os.path.basename(f): blob(f) for f in sorted(glob.glob(os.path.join(ROOT, "anime_recommendations_amd/csrc/*.h*")))}
+# the host code that shapes the launches of an op (batch plans, buffer sizes) is part of what was measured
+for f in ("ops.py", "engine.py", "ingest.py", "recs.py"):
+    sources[f] = blob(os.path.join(ROOT, "anime_recommendations_amd", f))
 for w in works:
     base = os.path.join(ROOT, "gpurun_out", rnd, w)
     name = NAMES.get(w, w)

@@ -54,6 +54,7 @@ def _worker(rank, world, port, out_dir, mode="sharded", backend="gloo"):
         vl, vm = eng.evaluate(tu[:500], ta[:500], tt[:500])
         Ufull = eng.U.cpu().numpy()
         Aloc = eng.A.cpu()
+        opt = eng.optimizer_state(iterations=n_steps)       # collective: the full-table Adam slots (model.save)
         for tbl in ([eng.A] if mode == "sharded" else [eng.A, eng.eng.U]):
             tbl = tbl.contiguous() if backend == "nccl" else tbl.cpu()
             a_all = [torch.empty_like(tbl) for _ in range(world)]
@@ -62,7 +63,9 @@ def _worker(rank, world, port, out_dir, mode="sharded", backend="gloo"):
         if rank == 0:
             rec = eng.read_state()
             np.savez(os.path.join(out_dir, "dist.npz"), U=Ufull, A=Aloc.numpy(), loss=loss, mse=mse, vl=vl, vm=vm,
-                     w=rec["w"], gamma=rec["gamma"], beta=rec["beta"], mov_var=rec["mov_var"])
+                     w=rec["w"], gamma=rec["gamma"], beta=rec["beta"], mov_var=rec["mov_var"],
+                     mU=opt["user_embedding/m"], vU=opt["user_embedding/v"], mA=opt["anime_embedding/m"],
+                     vA=opt["anime_embedding/v"])
         eng.close()
     finally:
         dist.destroy_process_group()
@@ -90,6 +93,12 @@ def _check_against_oracle(tmp_path):
     tol = lr * 2e-3 * len(ns)
     np.testing.assert_allclose(d["U"], st["U"], atol=tol)
     np.testing.assert_allclose(d["A"], st["A"], atol=tol)
+    # the gathered Adam slots (sharded: user rows re-interleaved; replicated_rs: every rank's row shard) are the
+    # single-process ones: m ~ 0.1 g per step, v ~ 1e-3 g^2
+    for k in ("mU", "mA"):
+        np.testing.assert_allclose(d[k], st[k], atol=2e-3 * max(np.abs(st[k]).max(), 1e-12), err_msg=k)
+    for k in ("vU", "vA"):
+        np.testing.assert_allclose(d[k], st[k], atol=4e-3 * max(np.abs(st[k]).max(), 1e-20), err_msg=k)
     h = st["head"]
     for k in ("w", "gamma", "beta"):
         assert abs(float(d[k]) - float(h[k])) < tol, k
