@@ -22,6 +22,7 @@ MAX_SEG = 16
 ABI_VERSION = 3
 TOPK_MAX_BATCHES = 64
 RCCL_ID_BYTES = 128
+LAZY_WINDOW = 8
 
 
 class AnirecError(RuntimeError):
@@ -55,12 +56,12 @@ class TrainDesc(C.Structure):
         ("n_user_rows", C.c_int32), ("n_anime_rows", C.c_int32), ("max_batch", C.c_int32),
         ("arena_steps", C.c_int32), ("dense_mode", C.c_int32), ("n_seg", C.c_int32),
         ("my_seg", C.c_int32), ("dense_rows", C.c_int32), ("l2", C.c_float), ("adam_row_lo", C.c_int32),
-        ("adam_row_hi", C.c_int32), ("pad1", C.c_int32),
+        ("adam_row_hi", C.c_int32), ("lazy", C.c_int32),
         ("W", C.c_void_p), ("M", C.c_void_p), ("V", C.c_void_p), ("rowmap", C.c_void_p),
         ("state", C.c_void_p), ("user_idx", C.c_void_p), ("anime_idx", C.c_void_p),
         ("rating", C.c_void_p), ("sched", C.c_void_p), ("n_steps", C.c_int32), ("pad2", C.c_int32),
         ("packets", C.c_void_p), ("dense_grad", C.c_void_p), ("workspace", C.c_void_p),
-        ("workspace_bytes", C.c_size_t),
+        ("workspace_bytes", C.c_size_t), ("lazy_state", C.c_void_p),
     ]
 
 
@@ -84,6 +85,7 @@ PROTOTYPES = {
     "anirec_device_name": (C.c_int, [C.c_char_p, _sz]),
     "anirec_packet_floats": (_sz, [_i32]),
     "anirec_train_workspace_bytes": (_sz, [_i32, _i32]),
+    "anirec_train_lazy_bytes": (_sz, [_i32]),
     "anirec_train_init_reg": (C.c_int, [_DP, _vp]),
     "anirec_train_prep": (C.c_int, [_DP, _i32, _i32, _vp]),
     "anirec_train_fwd": (C.c_int, [_DP, _vp]),

@@ -65,7 +65,10 @@ struct TrainWs {
   size_t hpart_stride;          // floats per parity
   StepPub *pub;                 // [2] step constants published by head workgroup 0
   int32_t *sel;                 // step index of the last head launch (read by bwd / densify / adam)
-  unsigned long long *ticks;    // [4][ANIREC_ADAM_BLOCKS][2] measurement stamps (fwd, head, bwd, adam), behind the arena
+  unsigned long long *ticks;    // [8][ANIREC_ADAM_BLOCKS][2] measurement stamps (fwd, head, bwd, adam, lazy catch-up,
+                                // lazy adam, lazy flush, lazy reduce), behind the arena
+  float *lzpart;                // [ANIREC_LAZY_WINDOW][2][ANIREC_ADAM_BLOCKS] lazy flush: per-step sum(W^2) block partials
+  float *lzring;                // [ANIREC_LAZY_WINDOW][2] lazy: {n, bce mean} of the open window's steps
   float *regpart;               // [2][2][ANIREC_ADAM_BLOCKS]: user-row / anime-row sum(W^2) partials
   float *P;                     // [2][2*capC][128] chunk partial rows
   float *S;                     // [2][2*capC]      chunk self-coefficient sums
@@ -109,7 +112,9 @@ __host__ inline TrainWs carve(void *base, int cap, int arena_steps) {
   w.slot_bytes = align_up(16) + 2 * align_up(sizeof(int32_t) * 2 * (size_t)cap) +
                  align_up(sizeof(int4) * 2 * (size_t)w.capC);
   w.arena = take(w.slot_bytes * (size_t)arena_steps);
-  w.ticks = (unsigned long long *)take(sizeof(unsigned long long) * 4 * 2 * ANIREC_ADAM_BLOCKS);
+  w.ticks = (unsigned long long *)take(sizeof(unsigned long long) * 8 * 2 * ANIREC_ADAM_BLOCKS);
+  w.lzpart = (float *)take(sizeof(float) * ANIREC_LAZY_WINDOW * 2 * ANIREC_ADAM_BLOCKS);
+  w.lzring = (float *)take(sizeof(float) * ANIREC_LAZY_WINDOW * 2);
   w.total = off;
   return w;
 }
@@ -806,7 +811,7 @@ __device__ __forceinline__ void bwd_chunk(const BwdArgs &a, const StepPub &pub, 
   reinterpret_cast<float4 *>(a.P)[pc * kRowVec + l] = acc;
   if (l == 0) {
     a.S[pc] = ssum;
-    if (rec.w > 0) a.rowmap[(size_t)par * a.rows + rec.x] = ((gc << 10) | (rec.w - 1)) + 1;
+    if (rec.w > 0 && a.rowmap != nullptr) a.rowmap[(size_t)par * a.rows + rec.x] = ((gc << 10) | (rec.w - 1)) + 1;
   }
 }
 
@@ -1027,7 +1032,11 @@ __device__ __forceinline__ void block_sq_partials(float sq, float sqa, float *sc
 // the end of step t (one workgroup of 256 threads): reduce the head partials, Adam on (w, b, gamma, beta), moving
 // statistics, History sums, cursors.  The L2 term of the loss is sum(W^2) of the weights step t READ: the partials
 // the launches of step t-1 (or init_reg) left in the other parity.
-__device__ __forceinline__ void finish_step(const AdamArgs &a, int par, float *scratch) {
+// kLazy (the lazy dense Adam): the L2 sums of the step are not known yet — the step's batch count and BCE mean go to
+// `ring` (slot step - w0) and k_lazy_reduce completes loss / reg_* when the window is flushed.
+template <bool kLazy = false>
+__device__ __forceinline__ void finish_step(const AdamArgs &a, int par, float *scratch, float *ring = nullptr,
+                                            int ring_slot = 0) {
   const StepPub pub = a.pub[par];
   const float *hpart = a.hpart + par * a.hpart_stride;
   anirec_state *st = a.state;
@@ -1037,11 +1046,13 @@ __device__ __forceinline__ void finish_step(const AdamArgs &a, int par, float *s
   const float4 *ru = reinterpret_cast<const float4 *>(a.regpart + (size_t)(pp * 2 + 0) * ANIREC_ADAM_BLOCKS);
   const float4 *ra = reinterpret_cast<const float4 *>(a.regpart + (size_t)(pp * 2 + 1) * ANIREC_ADAM_BLOCKS);
   float q[2] = {0.f, 0.f};
+  if (!kLazy) {
 #pragma unroll 2
-  for (int i4 = threadIdx.x; i4 < ANIREC_ADAM_BLOCKS / 4; i4 += 256) {
-    const float4 u = ru[i4], v = ra[i4];
-    q[0] += (u.x + u.y) + (u.z + u.w);
-    q[1] += (v.x + v.y) + (v.z + v.w);
+    for (int i4 = threadIdx.x; i4 < ANIREC_ADAM_BLOCKS / 4; i4 += 256) {
+      const float4 u = ru[i4], v = ra[i4];
+      q[0] += (u.x + u.y) + (u.z + u.w);
+      q[1] += (v.x + v.y) + (v.z + v.w);
+    }
   }
   float am[4], av[4];
 #pragma unroll
@@ -1085,20 +1096,25 @@ __device__ __forceinline__ void finish_step(const AdamArgs &a, int par, float *s
     st->beta = p4[3];
     st->mov_mean = mmean - (mmean - pub.mu) * kBnDecay;
     st->mov_var = mvar - (mvar - pub.var) * kBnDecay;
-    const float reg_u = q[0], reg_a = q[1];
-    const float reg = reg_u + reg_a;
-    st->reg_sumsq = reg;
-    st->reg_user_sumsq = reg_u;
-    st->reg_anime_sumsq = reg_a;
     st->bn_mu = pub.mu;
     st->bn_var = pub.var;
-    const float loss = (float)(L / n) + pub.l2 * reg;
-    st->last_loss = loss;
     st->last_mse = (float)(SE / n);
-    st->loss_wsum = o_loss + (double)loss * n;
     st->bce_wsum = o_bce + L;
-    st->reg_user_wsum = o_ru + (double)reg_u * n;
-    st->reg_anime_wsum = o_ra + (double)reg_a * n;
+    if (kLazy) {
+      ring[2 * ring_slot + 0] = (float)pub.n_total;
+      ring[2 * ring_slot + 1] = (float)(L / n);
+    } else {
+      const float reg_u = q[0], reg_a = q[1];
+      const float reg = reg_u + reg_a;
+      st->reg_sumsq = reg;
+      st->reg_user_sumsq = reg_u;
+      st->reg_anime_sumsq = reg_a;
+      const float loss = (float)(L / n) + pub.l2 * reg;
+      st->last_loss = loss;
+      st->loss_wsum = o_loss + (double)loss * n;
+      st->reg_user_wsum = o_ru + (double)reg_u * n;
+      st->reg_anime_wsum = o_ra + (double)reg_a * n;
+    }
     st->se_sum = o_se + SE;
     st->n_seen = o_n + n;
     st->step_bwd = pub.step;
@@ -1144,7 +1160,7 @@ __device__ __forceinline__ void adam_body(const AdamArgs &a, int bid, int nblock
   float *rp = a.regpart + (size_t)(par * 2) * ANIREC_ADAM_BLOCKS;
   block_sq_partials(sq, sqa, scratch, (a.parts & 1) ? rp + bid : nullptr,
                     (a.parts & 2) ? rp + ANIREC_ADAM_BLOCKS + bid : nullptr);
-  if (bid == 0 && (a.parts & 4)) finish_step(a, par, scratch);
+  if (bid == 0 && (a.parts & 4)) finish_step<false>(a, par, scratch);
 }
 
 template <bool kNT>
@@ -1152,6 +1168,336 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
   __shared__ float scratch[kHeadCols * 16];
   tick(a.ticks, 0);
   adam_body<kNT>(a, blockIdx.x, gridDim.x, scratch);
+  tick(a.ticks, 1);
+}
+
+// ------------------------------------------------------------------------------------
+// lazy dense Adam (one GPU; include/anirec.h, "LAZY DENSE ADAM")
+// ------------------------------------------------------------------------------------
+constexpr int kLzWin = ANIREC_LAZY_WINDOW;
+
+struct LazyState {
+  int32_t *row_step;  // [rows] the step every row has been updated to (rows are current at the window's start)
+  float *rowsq;       // [rows][kLzWin] sum(W_s^2) of the row for the window's steps it has already taken
+};
+__host__ __device__ inline LazyState lazy_carve(void *base, int rows) {
+  LazyState z;
+  z.row_step = (int32_t *)base;
+  z.rowsq = (float *)((char *)base + ((sizeof(int32_t) * (size_t)rows + 255) / 256 * 256));
+  return z;
+}
+
+struct LazyArgs {
+  float *W, *M, *V;
+  int rows, n_user_rows;
+  LazyState z;
+  const anirec_step *sched;
+  int n_steps;
+  anirec_state *state;
+  int32_t *w0;  // device word: first step of the open window
+  float two_l2, l2;
+  char *arena;
+  size_t slot_bytes;
+  int cap, capC, arena_steps;
+  float *lzpart, *lzring, *regpart;
+  unsigned long long *ticks;
+};
+
+struct Row3 {
+  float4 w, m, v;
+};
+
+// pending pure-L2 steps [j0, j1) (window-relative) of one row, a float4 per lane: g = 2 lambda W exactly as the
+// dense kernel forms it for a row no rating touched; sq[j] receives this lane's part of sum(W_s^2), the weights
+// step s READ
+// the dense kernel's gradient of a row no rating touched, grad_total(0, 0, w, 2 lambda) = (0 - 0 w) + 2 lambda w:
+// (0 - 0 w) is +0 for every finite w, so it is (2 lambda w) + 0 — the "+ 0" kept because it turns a -0 product into
+// the +0 the dense expression yields (bit-identical tables, zeros included)
+__device__ __forceinline__ float l2_only_grad(float w, float two_l2) {
+#pragma clang fp contract(off)
+  return two_l2 * w + 0.0f;
+}
+
+__device__ __forceinline__ void lazy_one_step(Row3 &x, float alpha, float two_l2, float &sq) {
+  sq = x.w.x * x.w.x + x.w.y * x.w.y + x.w.z * x.w.z + x.w.w * x.w.w;
+  const float gx = l2_only_grad(x.w.x, two_l2), gy = l2_only_grad(x.w.y, two_l2), gz = l2_only_grad(x.w.z, two_l2),
+              gw = l2_only_grad(x.w.w, two_l2);
+  adam_elem(x.w.x, x.m.x, x.v.x, gx, alpha);
+  adam_elem(x.w.y, x.m.y, x.v.y, gy, alpha);
+  adam_elem(x.w.z, x.m.z, x.v.z, gz, alpha);
+  adam_elem(x.w.w, x.m.w, x.v.w, gw, alpha);
+}
+
+__device__ __forceinline__ void lazy_replay(Row3 &x, int j0, int j1, const float (&alpha)[kLzWin], float two_l2,
+                                            float (&sq)[kLzWin]) {
+  if (__all(j0 <= 0 && j1 >= kLzWin)) {  // the common case (a row untouched for a whole window): no predication
+#pragma unroll
+    for (int j = 0; j < kLzWin; ++j) lazy_one_step(x, alpha[j], two_l2, sq[j]);
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < kLzWin; ++j) {
+    if (__any(j >= j0 && j < j1)) {  // wave-uniform skip, then per-lane selection of the stepped values
+      Row3 y = x;
+      float q;
+      lazy_one_step(y, alpha[j], two_l2, q);
+      if (j >= j0 && j < j1) {
+        x = y;
+        sq[j] = q;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void lazy_alphas(const LazyArgs &a, int w0, int nj, float (&alpha)[kLzWin]) {
+#pragma unroll
+  for (int j = 0; j < kLzWin; ++j) alpha[j] = (j < nj && w0 + j < a.n_steps) ? a.sched[w0 + j].alpha : 0.f;
+}
+
+// the distinct row a half-wave of the chunk-table grid owns (first chunk of a row's run), or -1
+__device__ __forceinline__ int lazy_chunk_row(const LazyArgs &a, int step, int &gc, int &nch) {
+  const int hw = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int T = hw >= a.capC ? 1 : 0;
+  const int c = hw - T * a.capC;
+  Slot sl = slot_of(a.arena, a.slot_bytes, a.cap, a.capC, step % a.arena_steps);
+  if (hw >= 2 * a.capC || c >= sl.nchunks[T]) return -1;
+  const int4 rec = sl.chunks[T * a.capC + c];
+  if (rec.w <= 0) return -1;
+  gc = T * a.capC + c;
+  nch = rec.w;
+  return rec.x;
+}
+
+// before fwd(t): the rows batch t touches take their pending L2-only steps, so that fwd / bwd read current rows
+__global__ __launch_bounds__(256) void k_lazy_catchup(LazyArgs a) {
+  tick(a.ticks, 0);
+  const int step = a.state->step_fwd;
+  const int w0 = a.w0[0];
+  const int l = threadIdx.x & 31;
+  int gc, nch;
+  const int row = lazy_chunk_row(a, step, gc, nch);
+  if (row >= 0) {
+    const int ta = a.z.row_step[row];
+    if (ta < step) {
+      const size_t e = (size_t)row * kRowVec + l;
+      Row3 x;
+      x.w = reinterpret_cast<const float4 *>(a.W)[e];
+      x.m = reinterpret_cast<const float4 *>(a.M)[e];
+      x.v = reinterpret_cast<const float4 *>(a.V)[e];
+      float alpha[kLzWin], sq[kLzWin];
+      lazy_alphas(a, w0, step - w0, alpha);
+#pragma unroll
+      for (int j = 0; j < kLzWin; ++j) sq[j] = 0.f;
+      lazy_replay(x, ta - w0, step - w0, alpha, a.two_l2, sq);
+      reinterpret_cast<float4 *>(a.W)[e] = x.w;
+      reinterpret_cast<float4 *>(a.M)[e] = x.m;
+      reinterpret_cast<float4 *>(a.V)[e] = x.v;
+      float mine = 0.f;
+#pragma unroll
+      for (int j = 0; j < kLzWin; ++j) {
+        const float t = halfwave_sum(sq[j]);
+        if (l == j) mine = t;
+      }
+      if (l >= ta - w0 && l < step - w0) a.z.rowsq[(size_t)row * kLzWin + l] = mine;
+      if (l == 0) a.z.row_step[row] = step;
+    }
+  }
+  tick(a.ticks, 1);
+}
+
+// after bwd(t): step t on the rows the batch touched (chunk gradient - s W + 2 lambda W), the step finish in
+// workgroup 0.  Same operations, same order as the dense kernel's row_issue / row_finish for a touched row.
+__global__ __launch_bounds__(256) void k_lazy_adam(LazyArgs a, AdamArgs d) {
+  __shared__ float scratch[kHeadCols * 16];
+  tick(a.ticks, 0);
+  const int step = d.sel[0];
+  const int par = step & 1;
+  const int w0 = a.w0[0];
+  const float alpha = d.pub[par].alpha;
+  const int l = threadIdx.x & 31;
+  int gc, nch;
+  const int row = lazy_chunk_row(a, step, gc, nch);
+  if (row >= 0) {
+    const size_t e = (size_t)row * kRowVec + l;
+    const float4 *P4 = reinterpret_cast<const float4 *>(d.P) + (size_t)par * 2 * d.capC * kRowVec;
+    const float *S = d.S + (size_t)par * 2 * d.capC;
+    float4 w = reinterpret_cast<const float4 *>(a.W)[e];
+    float4 m = reinterpret_cast<const float4 *>(a.M)[e];
+    float4 v = reinterpret_cast<const float4 *>(a.V)[e];
+    float4 g = P4[(size_t)gc * kRowVec + l];
+    float sc = S[gc];
+    if (nch > 1) add_chunks<4>(P4, S, gc + 1, gc + nch, l, g, sc);
+    const float sq = halfwave_sum(w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w);
+    g.x = grad_total(g.x, sc, w.x, a.two_l2);
+    g.y = grad_total(g.y, sc, w.y, a.two_l2);
+    g.z = grad_total(g.z, sc, w.z, a.two_l2);
+    g.w = grad_total(g.w, sc, w.w, a.two_l2);
+    adam_elem(w.x, m.x, v.x, g.x, alpha);
+    adam_elem(w.y, m.y, v.y, g.y, alpha);
+    adam_elem(w.z, m.z, v.z, g.z, alpha);
+    adam_elem(w.w, m.w, v.w, g.w, alpha);
+    reinterpret_cast<float4 *>(a.W)[e] = w;
+    reinterpret_cast<float4 *>(a.M)[e] = m;
+    reinterpret_cast<float4 *>(a.V)[e] = v;
+    if (l == 0) {
+      a.z.rowsq[(size_t)row * kLzWin + (step - w0)] = sq;
+      a.z.row_step[row] = step + 1;
+    }
+  }
+  if (blockIdx.x == 0) finish_step<true>(d, par, scratch, a.lzring, step - w0);
+  tick(a.ticks, 1);
+}
+
+// every kLzWin steps and at the end of a run: every row takes its pending steps (one pass over W, M, V for the
+// whole window); per step and table the workgroup's sum(W_s^2) — recorded by the earlier kernels for the steps a row
+// had already taken, computed here for the replayed ones — goes to lzpart, the sum(W^2) of the weights as they are
+// left to the dense path's regpart (both parities: whichever step comes next reads it)
+template <bool kNT>
+__global__ __launch_bounds__(256) void k_lazy_flush(LazyArgs a) {
+  __shared__ float red[2 * kLzWin + 2][4];
+  tick(a.ticks, 0);
+  const int upto = a.state->step_fwd;
+  const int w0 = a.w0[0];
+  const int nj = upto - w0;
+  const int l = threadIdx.x & 31;
+  const int nhw = gridDim.x * 8;
+  float alpha[kLzWin];
+  lazy_alphas(a, w0, nj, alpha);
+  float acc[2][kLzWin];
+#pragma unroll
+  for (int j = 0; j < kLzWin; ++j) acc[0][j] = acc[1][j] = 0.f;
+  float fin[2] = {0.f, 0.f};
+  // one row per half-wave and iteration, the NEXT row's W / M / V and step word in flight while this one's pending
+  // steps are computed (8 steps x 4 elements of IEEE sqrt + divide: ~1 200 instructions per row — about as long as
+  // the row's memory time, so the two must overlap)
+  auto load_row = [&](int r, Row3 &x) {
+    const size_t e = (size_t)r * kRowVec + l;
+    const float4 *Wp = reinterpret_cast<const float4 *>(a.W) + e, *Mp = reinterpret_cast<const float4 *>(a.M) + e,
+                 *Vp = reinterpret_cast<const float4 *>(a.V) + e;
+    x.w = kNT ? ld_nt(Wp) : *Wp;
+    x.m = kNT ? ld_nt(Mp) : *Mp;
+    x.v = kNT ? ld_nt(Vp) : *Vp;
+  };
+  int r = blockIdx.x * 8 + (threadIdx.x >> 5);
+  Row3 nx;
+  nx.w = nx.m = nx.v = make_float4(0.f, 0.f, 0.f, 0.f);
+  int ta_n = 0;
+  if (r < a.rows) {
+    ta_n = a.z.row_step[r];
+    load_row(r, nx);
+  }
+  for (; r < a.rows; r += nhw) {
+    Row3 x = nx;
+    const int ta = ta_n;
+    const int rn = r + nhw;
+    if (rn < a.rows) {
+      ta_n = a.z.row_step[rn];
+      load_row(rn, nx);
+    }
+    const int jt = ta - w0;  // steps [0, jt) of the window are on record, [jt, nj) are pending
+    const size_t e = (size_t)r * kRowVec + l;
+    float rec = 0.f;
+    if (l < jt) rec = a.z.rowsq[(size_t)r * kLzWin + l];  // lane j holds the recorded sum of step j
+    float sq[kLzWin];
+#pragma unroll
+    for (int j = 0; j < kLzWin; ++j) sq[j] = 0.f;
+    if (jt < nj) {
+      lazy_replay(x, jt, nj, alpha, a.two_l2, sq);
+      if (kNT) {
+        st_nt(reinterpret_cast<float4 *>(a.W) + e, x.w);
+        st_nt(reinterpret_cast<float4 *>(a.M) + e, x.m);
+        st_nt(reinterpret_cast<float4 *>(a.V) + e, x.v);
+      } else {
+        reinterpret_cast<float4 *>(a.W)[e] = x.w;
+        reinterpret_cast<float4 *>(a.M)[e] = x.m;
+        reinterpret_cast<float4 *>(a.V)[e] = x.v;
+      }
+      if (l == 0) a.z.row_step[r] = upto;
+    }
+    const int tab = r < a.n_user_rows ? 0 : 1;
+#pragma unroll
+    for (int j = 0; j < kLzWin; ++j) {
+      const float add = sq[j] + (l == j ? rec : 0.f);  // lane parts of a replayed step, or the recorded row sum
+      if (tab == 0) acc[0][j] += add; else acc[1][j] += add;
+    }
+    const float fq = x.w.x * x.w.x + x.w.y * x.w.y + x.w.z * x.w.z + x.w.w * x.w.w;
+    if (tab == 0) fin[0] += fq; else fin[1] += fq;
+  }
+  // block sums in a fixed order: lanes -> waves -> the four waves
+  const int wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < kLzWin; ++j) {
+      const float v = wave_sum(acc[t][j]);
+      if ((threadIdx.x & 63) == 0) red[t * kLzWin + j][wv] = v;
+    }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float v = wave_sum(fin[t]);
+    if ((threadIdx.x & 63) == 0) red[2 * kLzWin + t][wv] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * kLzWin) {
+    const int t = threadIdx.x / kLzWin, j = threadIdx.x % kLzWin;
+    a.lzpart[((size_t)j * 2 + t) * ANIREC_ADAM_BLOCKS + blockIdx.x] =
+        ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
+  } else if (threadIdx.x < 2 * kLzWin + 2) {
+    const int t = threadIdx.x - 2 * kLzWin;
+    const float v = ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
+    a.regpart[(size_t)(0 * 2 + t) * ANIREC_ADAM_BLOCKS + blockIdx.x] = v;
+    a.regpart[(size_t)(1 * 2 + t) * ANIREC_ADAM_BLOCKS + blockIdx.x] = v;
+  }
+  tick(a.ticks, 1);
+}
+
+// one workgroup of 16 waves: wave (2 j + table) sums the flush's block partials of step j in a fixed order, then
+// one thread completes the History sums of the window's steps in step order and opens the next window
+__global__ __launch_bounds__(1024) void k_lazy_reduce(LazyArgs a) {
+  __shared__ float reg[kLzWin][2];
+  tick(a.ticks, 0);
+  const int upto = a.state->step_fwd;
+  const int w0 = a.w0[0];
+  const int nj = upto - w0;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  static_assert(2 * kLzWin <= 16, "one wave per (step, table)");
+  if (wv < 2 * kLzWin) {
+    // wv = 2 j + table; 32 x 16 B per lane, every load issued before the first add (a dependent scalar loop
+    // measured 38 us for this workgroup)
+    const float4 *p = reinterpret_cast<const float4 *>(a.lzpart + (size_t)wv * ANIREC_ADAM_BLOCKS);
+    constexpr int kV = ANIREC_ADAM_BLOCKS / 4 / 64;
+    float4 v[kV];
+#pragma unroll
+    for (int i = 0; i < kV; ++i) v[i] = p[lane + 64 * i];
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < kV; ++i) sacc += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    sacc = wave_sum(sacc);
+    if (lane == 0) reg[wv >> 1][wv & 1] = sacc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && nj > 0) {
+    anirec_state *st = a.state;
+    double o_loss = st->loss_wsum, o_ru = st->reg_user_wsum, o_ra = st->reg_anime_wsum;
+    float loss = 0.f, ru = 0.f, ra = 0.f;
+    for (int j = 0; j < nj && j < kLzWin; ++j) {
+      const double n = (double)a.lzring[2 * j + 0];
+      ru = reg[j][0];
+      ra = reg[j][1];
+      loss = a.lzring[2 * j + 1] + a.l2 * (ru + ra);
+      o_loss += (double)loss * n;
+      o_ru += (double)ru * n;
+      o_ra += (double)ra * n;
+    }
+    st->loss_wsum = o_loss;
+    st->reg_user_wsum = o_ru;
+    st->reg_anime_wsum = o_ra;
+    st->last_loss = loss;
+    st->reg_sumsq = ru + ra;
+    st->reg_user_sumsq = ru;
+    st->reg_anime_sumsq = ra;
+    a.w0[0] = upto;
+  }
   tick(a.ticks, 1);
 }
 
@@ -1411,8 +1757,9 @@ static BwdArgs bwd_args(const anirec_train_desc *d, const TrainWs &w) {
   return a;
 }
 
-static int launch_bwd_only(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
-  const BwdArgs a = bwd_args(d, w);
+static int launch_bwd_only(const anirec_train_desc *d, const TrainWs &w, hipStream_t s, bool lazy = false) {
+  BwdArgs a = bwd_args(d, w);
+  if (lazy) a.rowmap = nullptr;  // the lazy update walks the chunk table itself: no row map to fill (or to clear)
   hipLaunchKernelGGL(k_bwd, dim3((2 * w.capC + 7) / 8), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
@@ -1494,6 +1841,67 @@ static int launch_adam(const anirec_train_desc *d, const TrainWs &w, hipStream_t
   return launch_adam_full(d, w, s, 0);
 }
 
+// ---- lazy dense Adam: host side ----
+static inline bool lazy_on(const anirec_train_desc *d) {
+  return d->lazy != 0 && d->lazy_state != nullptr && d->dense_mode == 0 && d->n_seg == 1;
+}
+
+static LazyArgs lazy_args(const anirec_train_desc *d, const TrainWs &w, int ticks_slot) {
+  LazyArgs a;
+  a.W = d->W;
+  a.M = d->M;
+  a.V = d->V;
+  a.rows = table_rows(d);
+  a.n_user_rows = d->n_user_rows;
+  a.z = lazy_carve(d->lazy_state, table_rows(d));
+  a.sched = d->sched;
+  a.n_steps = d->n_steps;
+  a.state = d->state;
+  a.w0 = w.sel + 1;
+  a.two_l2 = 2.0f * d->l2;
+  a.l2 = d->l2;
+  a.arena = w.arena;
+  a.slot_bytes = w.slot_bytes;
+  a.cap = w.cap;
+  a.capC = w.capC;
+  a.arena_steps = w.arena_steps;
+  a.lzpart = w.lzpart;
+  a.lzring = w.lzring;
+  a.regpart = w.regpart;
+  a.ticks = ticks_of(w, ticks_slot);
+  return a;
+}
+
+// every row is current as of `first_step` (each anirec_trainer_run call ends flushed): open a window there
+static int lazy_begin(const anirec_train_desc *d, const TrainWs &w, int first_step, hipStream_t s) {
+  const LazyState z = lazy_carve(d->lazy_state, table_rows(d));
+  ANIREC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)z.row_step, first_step, (size_t)table_rows(d), s));
+  ANIREC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(w.sel + 1), first_step, 1, s));
+  return ANIREC_OK;
+}
+
+static int lazy_step(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
+  const int grid = (2 * w.capC + 7) / 8;
+  hipLaunchKernelGGL(k_lazy_catchup, dim3(grid), dim3(256), 0, s, lazy_args(d, w, 4));
+  int e;
+  if ((e = launch_fwd(d, w, s))) return e;
+  if ((e = launch_head(d, w, s))) return e;
+  if ((e = launch_bwd_only(d, w, s, true))) return e;
+  AdamArgs aa = adam_args(d, w);
+  aa.ticks = nullptr;
+  hipLaunchKernelGGL(k_lazy_adam, dim3(grid), dim3(256), 0, s, lazy_args(d, w, 5), aa);
+  return (int)hipGetLastError();
+}
+
+static int lazy_flush(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
+  if (stream_nt(d))
+    hipLaunchKernelGGL((k_lazy_flush<true>), dim3(adam_grid(d)), dim3(256), 0, s, lazy_args(d, w, 6));
+  else
+    hipLaunchKernelGGL((k_lazy_flush<false>), dim3(adam_grid(d)), dim3(256), 0, s, lazy_args(d, w, 6));
+  hipLaunchKernelGGL(k_lazy_reduce, dim3(1), dim3(1024), 0, s, lazy_args(d, w, 7));
+  return (int)hipGetLastError();
+}
+
 }  // namespace anirec
 
 using namespace anirec;
@@ -1502,6 +1910,11 @@ extern "C" {
 
 // c[pcap] | t[pcap] | {count,0,0,0}, pcap = max_batch rounded up to 4 floats (16-B aligned rows)
 size_t anirec_packet_floats(int32_t max_batch) { return 2 * (size_t)packet_cap(max_batch) + 4; }
+
+size_t anirec_train_lazy_bytes(int32_t rows) {
+  if (rows < 1) return 0;
+  return (sizeof(int32_t) * (size_t)rows + 255) / 256 * 256 + sizeof(float) * (size_t)rows * ANIREC_LAZY_WINDOW;
+}
 
 size_t anirec_train_workspace_bytes(int32_t max_batch, int32_t arena_steps) {
   if (max_batch < 1 || max_batch > ANIREC_MAX_BATCH || arena_steps < 2) return 0;
@@ -1589,16 +2002,17 @@ int anirec_train_adam(const anirec_train_desc *d, void *stream) {
 
 // Measurement hook (bench.py).  While armed, every training kernel launched through this library stamps the
 // constant-clock (100 MHz) time of each workgroup's first and last instruction into the workspace; this call
-// synchronises the stream, returns per kernel (0 fwd or fwd+head, 1 head, 2 bwd, 3 adam) max(end) - min(start) over
+// synchronises the stream, returns per kernel (0 fwd, 1 head, 2 bwd, 3 adam, 4 lazy catch-up, 5 lazy adam, 6 lazy
+// flush, 7 lazy reduce) max(end) - min(start) over
 // the workgroups of the launches made since the last call [us; -1 = not launched], clears the stamps and arms
 // (enable != 0) or disarms.  Call it once per step: the stamps of two launches of one kernel would merge.
-int anirec_train_stage_ticks(const anirec_train_desc *d, int32_t enable, float *us4_host, void *stream) {
+int anirec_train_stage_ticks(const anirec_train_desc *d, int32_t enable, float *us8_host, void *stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   TrainWs w = carve(d->workspace, d->max_batch, d->arena_steps);
-  const size_t n = (size_t)4 * 2 * ANIREC_ADAM_BLOCKS;
-  if (us4_host) {
+  const size_t n = (size_t)8 * 2 * ANIREC_ADAM_BLOCKS;
+  if (us8_host) {
     unsigned long long *h = new (std::nothrow) unsigned long long[n];
     if (!h) return ANIREC_EINVAL;
     hipError_t e = hipStreamSynchronize(s);
@@ -1607,14 +2021,14 @@ int anirec_train_stage_ticks(const anirec_train_desc *d, int32_t enable, float *
       delete[] h;
       return (int)e;
     }
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 8; ++k) {
       unsigned long long lo = ~0ull, hi = 0ull;
       for (int b = 0; b < ANIREC_ADAM_BLOCKS; ++b) {
         const unsigned long long t0 = h[((size_t)k * ANIREC_ADAM_BLOCKS + b) * 2], t1 = h[((size_t)k * ANIREC_ADAM_BLOCKS + b) * 2 + 1];
         if (t0 != 0ull && t0 < lo) lo = t0;
         if (t1 > hi) hi = t1;
       }
-      us4_host[k] = hi > 0ull && lo != ~0ull && hi >= lo ? (float)((double)(hi - lo) * 0.01) : -1.0f;
+      us8_host[k] = hi > 0ull && lo != ~0ull && hi >= lo ? (float)((double)(hi - lo) * 0.01) : -1.0f;
     }
     delete[] h;
   }
@@ -1934,6 +2348,7 @@ static int front_of_step(anirec_trainer *t, hipStream_t s) {
 }
 
 static int one_step(anirec_trainer *t, hipStream_t s) {
+  if (lazy_on(&t->d)) return lazy_step(&t->d, t->ws, s);
   int e;
   if ((e = front_of_step(t, s))) return e;
   return launch_adam(&t->d, t->ws, s);
@@ -1953,6 +2368,12 @@ int anirec_trainer_run(anirec_trainer *t, int32_t first_step, int32_t n_steps, i
   if (G > 32) G = 32;
   int done = 0;
   const bool graph = use_graph && s != nullptr && G >= 4 && n_steps >= G && !g_ticks_on;  // (stamped steps run eagerly)
+  const bool lazy = lazy_on(&t->d);
+  if (lazy) {
+    const int e = lazy_begin(&t->d, t->ws, first_step, s);
+    if (e) return e;
+  }
+  int open = 0;  // lazy: steps since the last flush (eager part)
   if (graph) {
     if (!t->exec || t->graph_steps != G) {
       if (t->exec) (void)hipGraphExecDestroy(t->exec);
@@ -1960,8 +2381,13 @@ int anirec_trainer_run(anirec_trainer *t, int32_t first_step, int32_t n_steps, i
       hipGraph_t g = nullptr;
       if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess)
         return ANIREC_ECAPTURE;
+      const bool lazy = lazy_on(&t->d);
       int e = launch_prep(&t->d, t->ws, G, G, true, s);  // steps cursor+G .. cursor+2G
-      for (int i = 0; i < G && !e; ++i) e = one_step(t, s);
+      for (int i = 0; i < G && !e; ++i) {
+        e = one_step(t, s);
+        // lazy: a flush every kLzWin steps and at the end of the block (a replay leaves the tables up to date)
+        if (!e && lazy && ((i + 1) % kLzWin == 0 || i + 1 == G)) e = lazy_flush(&t->d, t->ws, s);
+      }
       hipError_t ce = hipStreamEndCapture(s, &g);
       if (e || ce != hipSuccess || !g) {
         if (g) (void)hipGraphDestroy(g);
@@ -1993,6 +2419,10 @@ int anirec_trainer_run(anirec_trainer *t, int32_t first_step, int32_t n_steps, i
     for (int i = 0; i < blk; ++i) {
       int e = one_step(t, s);
       if (e) return e;
+      if (lazy && (++open == kLzWin || (i + 1 == blk && done + blk >= n_steps))) {
+        if ((e = lazy_flush(&t->d, t->ws, s))) return e;
+        open = 0;
+      }
     }
     done += blk;
   }

@@ -29,11 +29,15 @@ def _dev_bytes(n, device):
 
 class TrainEngine:
     def __init__(self, n_user_rows, n_anime_rows, max_batch, l2=1e-4, arena_steps=64,
-                 device="cuda:0", n_seg=1, my_seg=0, dense_mode=0, row_pad=1, adam_rows=None):
+                 device="cuda:0", n_seg=1, my_seg=0, dense_mode=0, row_pad=1, adam_rows=None, lazy=None):
         """dense_mode: 0 one GPU; 1 user-sharded DP (anime gradient through ``dense_grad``); 2 replicated
         tables (every gradient through ``dense_grad``).  row_pad: the tables and the dense buffer are
         allocated with their row count rounded up to a multiple of it (equal reduce-scatter / all-gather
-        shards).  adam_rows: (lo, hi) row shard this rank's Adam updates in mode 2, None = all."""
+        shards).  adam_rows: (lo, hi) row shard this rank's Adam updates in mode 2, None = all.
+        lazy: the lazy dense Adam of ``run`` (include/anirec.h: rows a batch does not touch take their L2-only steps
+        later, several at a time; tables and Adam state bit-identical to the dense update).  None = automatic: one
+        GPU and tables of at least 8 batches' worth of rows (below that most rows are touched every few steps and
+        the plain dense stream is faster); ANIREC_LAZY_ADAM=0/1 overrides."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.AnirecError("no GPU: the anime_recommendations_amd hot path needs an MI355X")
@@ -66,6 +70,12 @@ class TrainEngine:
         self.dense_rows = (carried + row_pad - 1) // row_pad * row_pad
         self.dense_grad = (torch.zeros(self.dense_rows * (DIM + 1), dtype=torch.float32, device=dev)
                            if self.dense_mode else None)
+        if lazy is None:
+            import os
+            env = os.environ.get("ANIREC_LAZY_ADAM")
+            lazy = (env != "0") and (env == "1" or self.rows >= 8 * self.max_batch)
+        self.lazy = bool(lazy) and self.dense_mode == 0 and self.n_seg == 1
+        self.lazy_state = (_dev_bytes(int(self.lib.anirec_train_lazy_bytes(self.rows)), dev) if self.lazy else None)
         self._stepper = None
         self.stream = torch.cuda.Stream(device=dev)
         self.user_idx = self.anime_idx = self.rating = self.sched = None
@@ -149,6 +159,7 @@ class TrainEngine:
         d.packets = _lib.ptr(self.packets)
         d.dense_grad = _lib.ptr(self.dense_grad)
         d.workspace, d.workspace_bytes = _lib.ptr(self.workspace), self.workspace.numel()
+        d.lazy, d.lazy_state = int(self.lazy), _lib.ptr(self.lazy_state)
         self._desc = d
         if self._trainer is not None:
             _lib.check(self.lib.anirec_trainer_destroy(self._trainer), "anirec_trainer_destroy")
@@ -224,13 +235,14 @@ class TrainEngine:
         _lib.check(self.lib.anirec_train_adam_part(C.byref(self.desc), 2, self._sp()), "anirec_train_adam_part")
 
     def stage_ticks(self, enable=True, read=True):
-        """Measurement hook (bench.py): in-kernel constant-clock stamps.  Returns {"fwd", "head", "bwd", "adam"} ->
+        """Measurement hook (bench.py): in-kernel constant-clock stamps.  Returns {"fwd", "head", "bwd", "adam", "lazy_*"} ->
         duration [us] of the launches made since the last call (None = not launched), clears the stamps and arms /
         disarms.  Synchronises."""
-        us = (C.c_float * 4)()
+        us = (C.c_float * 8)()
         _lib.check(self.lib.anirec_train_stage_ticks(C.byref(self.desc), int(bool(enable)), us if read else None,
                                                      self._sp()), "anirec_train_stage_ticks")
-        return {k: (float(us[i]) if us[i] >= 0 else None) for i, k in enumerate(("fwd", "head", "bwd", "adam"))} if read else None
+        names = ("fwd", "head", "bwd", "adam", "lazy_catchup", "lazy_adam", "lazy_flush", "lazy_reduce")
+        return {k: (float(us[i]) if us[i] >= 0 else None) for i, k in enumerate(names)} if read else None
 
     # ---- multi-GPU step halves: one C call each, the collectives go between them ------------
     def _get_stepper(self):
@@ -341,8 +353,10 @@ def workspace_layout(max_batch, arena_steps):
     lay["slot_sidx"] = 256
     lay["slot_oth"] = 256 + a1
     lay["slot_chunks"] = 256 + 2 * a1
-    lay["ticks"] = (off + lay["slot_bytes"] * arena_steps, 8 * 4 * 2 * _lib.ADAM_BLOCKS)
-    lay["total"] = lay["ticks"][0] + lay["ticks"][1]
+    lay["ticks"] = (off + lay["slot_bytes"] * arena_steps, 8 * 8 * 2 * _lib.ADAM_BLOCKS)
+    lay["lzpart"] = (lay["ticks"][0] + lay["ticks"][1], 4 * _lib.LAZY_WINDOW * 2 * _lib.ADAM_BLOCKS)
+    lay["lzring"] = (lay["lzpart"][0] + lay["lzpart"][1], _align(4 * _lib.LAZY_WINDOW * 2))
+    lay["total"] = lay["lzring"][0] + lay["lzring"][1]
     return lay
 
 

@@ -38,6 +38,7 @@ extern "C" {
 #define ANIREC_MAX_TOPK 128     /* k limit of the fused top-k kernels */
 #define ANIREC_MAX_SEG 16       /* max head packets (ranks of one node) */
 #define ANIREC_TOPK_MAX_BATCHES 64 /* query batches of one anirec_cosine_topk_job */
+#define ANIREC_LAZY_WINDOW 8    /* steps between two flushes of the lazy dense Adam (anirec_trainer_run) */
 
 enum {
   ANIREC_OK = 0,
@@ -114,7 +115,8 @@ typedef struct anirec_train_desc {
   float l2;             /* lambda of embeddings_regularizer L2 (neural_network.py:73) */
   int32_t adam_row_lo;  /* mode 2: adam updates table rows [adam_row_lo, adam_row_hi) only (the caller */
   int32_t adam_row_hi;  /* all-gathers W afterwards); 0,0 = every row */
-  int32_t pad1;
+  int32_t lazy;         /* != 0 (one GPU only, `lazy_state` set): anirec_trainer_run defers the dense update of the rows
+                           a batch does not touch — see anirec_trainer_run */
   /* tables: rows [0,n_user_rows) users, then n_anime_rows anime; [rows][128] fp32.
    * W = embeddings, M/V = Adam first/second moments. */
   float *W, *M, *V;
@@ -133,12 +135,15 @@ typedef struct anirec_train_desc {
   float *dense_grad;    /* [dense_rows*128] gradients then [dense_rows] self-coefficient sums, or NULL */
   void *workspace;      /* >= anirec_train_workspace_bytes(max_batch, arena_steps); zero before first use */
   size_t workspace_bytes;
+  void *lazy_state;     /* lazy != 0: anirec_train_lazy_bytes(rows) bytes, zero before first use; else NULL */
 } anirec_train_desc;
 
 /* floats in one head packet: c[pcap], t[pcap], 4 ints {count,0,0,0}; pcap = max_batch rounded
  * up to a multiple of 4 */
 size_t anirec_packet_floats(int32_t max_batch);
 size_t anirec_train_workspace_bytes(int32_t max_batch, int32_t arena_steps);
+/* per-row state of the lazy dense Adam: the step each row has been updated to + its sum(W^2) of the window's steps */
+size_t anirec_train_lazy_bytes(int32_t table_rows);
 
 /* state.reg_sumsq <- sum(W^2) (both tables).  Call once after (re)loading weights. */
 int anirec_train_init_reg(const anirec_train_desc *d, void *stream);
@@ -206,6 +211,18 @@ int anirec_dist_comm_destroy(anirec_dist_comm *c);
  * eager launches. */
 int anirec_dist_run(anirec_dist_stepper *h, anirec_dist_comm *c, int32_t first_step, int32_t n_steps, int32_t use_graph,
                     void *stream);
+
+/* LAZY DENSE ADAM (desc->lazy).  Keras' Adam updates every row of both tables every step, because the L2 regulariser
+ * gives every row a gradient (2 lambda W) — 28 B/element/step of HBM traffic for rows the batch never touched.  Each
+ * element's update sequence is independent of every other element's, so the rows a batch does not touch can take
+ * their pure-L2 steps LATER, several at a time, in registers, with the same fp32 operations in the same order:
+ *   catch-up(t)  brings the rows batch t touches up to step t (their pending L2-only steps), before fwd(t) reads them;
+ *   sparse adam(t) applies step t (chunk gradient + 2 lambda W) to those rows only;
+ *   every ANIREC_LAZY_WINDOW steps (and at the end of every anirec_trainer_run call) a flush replays the pending
+ *   steps of every row — one streaming pass over W, M, V per window instead of one per step — and a reduce kernel
+ *   assembles the per-step sum(W^2) of the loss's L2 term from the per-row values the replays recorded.
+ * Tables, Adam moments and the scalar state are BIT-IDENTICAL to the dense path; the History loss agrees to fp32
+ * rounding of its L2 sum (another summation order).  Outside anirec_trainer_run the tables are always up to date. */
 
 /* Steps [first_step, first_step + n_steps) — prep, fwd, head, bwd, adam — on one GPU; first_step
  * must equal the device cursor state->step_fwd.  use_graph != 0 replays a captured hipGraph of

@@ -285,3 +285,48 @@ def test_long_horizon_graph_run_tracks_the_c_oracle():
     p_own = ops.predict_pairs(eng.U, eng.A, own, ui[:2000], ai[:2000]).cpu().numpy()
     assert np.abs(p_own - po).max() < 1e-3
     eng.close()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_lazy_adam_is_bitwise_the_dense_update(use_graph):
+    """The lazy dense Adam (rows a batch does not touch take their L2-only steps later, several at a time: catch-up
+    before fwd, sparse step after bwd, a flush every 8 steps) must leave exactly the tables, Adam moments and scalar
+    state of the dense kernel — every element sees the same fp32 operations in the same order — through ragged run()
+    calls, windows cut short, graph replays and their eager tails; the History loss agrees to the rounding of its
+    L2 sum (another summation order)."""
+    from anime_recommendations_amd.engine import TrainEngine
+    n_u, n_a, B, steps = 5000, 900, 512, 77
+    U, A, ui, ai, t = _problem(17, n_u, n_a, B * steps - 100, 1.1)
+    n = len(ui)
+    starts, counts, alphas = _schedule(n, B, 2e-4)
+    engs = {}
+    for lazy in (False, True):
+        eng = TrainEngine(n_u, n_a, max_batch=B, arena_steps=16, lazy=lazy)
+        assert eng.lazy == lazy
+        eng.set_head(w=1.2)
+        eng.set_weights(U, A)
+        eng.set_epoch(ui, ai, t, starts, counts, alphas)
+        done = 0
+        for chunk in (1, 3, 8, 21, 9, 35):          # windows cut short, exactly full, several per call
+            done += eng.run(chunk, use_graph=use_graph, first_step=done)
+        assert done == len(counts) == steps
+        engs[lazy] = eng
+    d, z = engs[False], engs[True]
+    assert torch.equal(d.W, z.W) and torch.equal(d.M, z.M) and torch.equal(d.V, z.V)
+    rd, rz = d.read_state(), z.read_state()
+    for k in ("w", "b", "gamma", "beta", "adam_m", "adam_v", "mov_mean", "mov_var", "bn_mu", "bn_var", "last_mse",
+              "se_sum", "n_seen", "bce_wsum", "step_fwd"):
+        assert np.array_equal(rd[k], rz[k]), k
+    for k in ("last_loss", "reg_sumsq", "reg_user_sumsq", "reg_anime_sumsq"):
+        assert abs(float(rd[k]) - float(rz[k])) <= 2e-6 * abs(float(rd[k])) + 1e-7, k
+    for k in ("loss_wsum", "reg_user_wsum", "reg_anime_wsum"):
+        assert abs(float(rd[k]) - float(rz[k])) <= 2e-6 * abs(float(rd[k])), k
+    # a dense stage-by-stage step after lazy runs sees consistent L2 partials (the flush leaves them)
+    for eng in (d, z):
+        eng.set_epoch(ui, ai, t, starts, counts, alphas)
+        eng.run(5, use_graph=False)
+        eng.prep(5, 1)
+        eng.fwd(); eng.head(); eng.bwd(); eng.adam()
+    rd, rz = d.read_state(), z.read_state()
+    assert torch.equal(d.W, z.W) and abs(float(rd["last_loss"]) - float(rz["last_loss"])) <= 3e-6 * abs(float(rd["last_loss"]))
+    d.close(); z.close()
