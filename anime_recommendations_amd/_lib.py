@@ -93,7 +93,7 @@ PROTOTYPES = {
     "anirec_train_bwd": (C.c_int, [_DP, _vp]),
     "anirec_train_adam": (C.c_int, [_DP, _vp]),
     "anirec_train_adam_part": (C.c_int, [_DP, _i32, _vp]),
-    "anirec_train_stage_ticks": (C.c_int, [_DP, _i32, C.POINTER(C.c_float), _vp]),
+    "anirec_train_stage_ticks": (C.c_int, [_DP, _i32, C.POINTER(C.c_float), C.POINTER(C.c_int32), _vp]),
     "anirec_dist_stepper_create": (C.c_int, [_DP, C.POINTER(_vp)]),
     "anirec_dist_stepper_destroy": (C.c_int, [_vp]),
     "anirec_dist_step_mid": (C.c_int, [_vp, _vp]),

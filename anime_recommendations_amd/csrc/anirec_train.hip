@@ -1649,8 +1649,30 @@ static inline float *packet_ptr(const anirec_train_desc *d, int seg) {
 
 // measurement hook armed (anirec_train_stage_ticks): kernels stamp their workgroups' start / end times
 static bool g_ticks_on = false;
+static double g_tick_sum_us[8];  // per kernel: sum of the launch durations since the hook was last read
+static int g_tick_launches[8];
 static inline unsigned long long *ticks_of(const TrainWs &w, int kernel) {
   return g_ticks_on ? w.ticks + (size_t)kernel * 2 * ANIREC_ADAM_BLOCKS : nullptr;
+}
+// armed only: wait for the launch just made, turn its workgroups' stamps into ONE duration (max end - min start),
+// add it to the kernel's sum and clear the slot for the next launch
+static int ticks_collect(const TrainWs &w, int kernel, hipStream_t s) {
+  if (!g_ticks_on) return ANIREC_OK;
+  static unsigned long long h[2 * ANIREC_ADAM_BLOCKS];
+  unsigned long long *dev = w.ticks + (size_t)kernel * 2 * ANIREC_ADAM_BLOCKS;
+  ANIREC_HIP_CHECK(hipStreamSynchronize(s));
+  ANIREC_HIP_CHECK(hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost));
+  unsigned long long lo = ~0ull, hi = 0ull;
+  for (int b = 0; b < ANIREC_ADAM_BLOCKS; ++b) {
+    if (h[2 * b] != 0ull && h[2 * b] < lo) lo = h[2 * b];
+    if (h[2 * b + 1] > hi) hi = h[2 * b + 1];
+  }
+  if (hi > 0ull && lo != ~0ull && hi >= lo) {
+    g_tick_sum_us[kernel] += (double)(hi - lo) * 0.01;
+    g_tick_launches[kernel] += 1;
+  }
+  ANIREC_HIP_CHECK(hipMemsetAsync(dev, 0, sizeof(h), s));
+  return ANIREC_OK;
 }
 
 static FwdArgs fwd_args(const anirec_train_desc *d, const TrainWs &w) {
@@ -1677,6 +1699,7 @@ static int launch_fwd(const anirec_train_desc *d, const TrainWs &w, hipStream_t 
   const FwdArgs a = fwd_args(d, w);
   float *pk = packet_ptr(d, d->my_seg);
   hipLaunchKernelGGL(k_fwd, dim3((d->max_batch + 7) / 8), dim3(256), 0, s, a);
+  if (int te = ticks_collect(w, 0, s)) return te;
   if (d->n_seg > 1)
     hipLaunchKernelGGL(k_seg_stats, dim3(1), dim3(1024), 0, s, pk, packet_cap(d->max_batch), d->max_batch,
                        d->state);
@@ -1710,6 +1733,7 @@ static inline int head_blocks(const anirec_train_desc *d) {
 static int launch_head(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
   const HeadArgs a = head_args(d, w);
   hipLaunchKernelGGL(k_head, dim3(head_blocks(d)), dim3(kHeadThreads), 0, s, a);
+  if (int te = ticks_collect(w, 1, s)) return te;
   return (int)hipGetLastError();
 }
 
@@ -1761,6 +1785,7 @@ static int launch_bwd_only(const anirec_train_desc *d, const TrainWs &w, hipStre
   BwdArgs a = bwd_args(d, w);
   if (lazy) a.rowmap = nullptr;  // the lazy update walks the chunk table itself: no row map to fill (or to clear)
   hipLaunchKernelGGL(k_bwd, dim3((2 * w.capC + 7) / 8), dim3(256), 0, s, a);
+  if (int te = ticks_collect(w, 2, s)) return te;
   return (int)hipGetLastError();
 }
 
@@ -1834,6 +1859,7 @@ static int launch_adam_full(const anirec_train_desc *d, const TrainWs &w, hipStr
     hipLaunchKernelGGL((k_adam<true>), dim3(adam_grid(d)), dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL((k_adam<false>), dim3(adam_grid(d)), dim3(256), 0, s, a);
+  if (int te = ticks_collect(w, 3, s)) return te;
   return (int)hipGetLastError();
 }
 
@@ -1884,12 +1910,14 @@ static int lazy_step(const anirec_train_desc *d, const TrainWs &w, hipStream_t s
   const int grid = (2 * w.capC + 7) / 8;
   hipLaunchKernelGGL(k_lazy_catchup, dim3(grid), dim3(256), 0, s, lazy_args(d, w, 4));
   int e;
+  if ((e = ticks_collect(w, 4, s))) return e;
   if ((e = launch_fwd(d, w, s))) return e;
   if ((e = launch_head(d, w, s))) return e;
   if ((e = launch_bwd_only(d, w, s, true))) return e;
   AdamArgs aa = adam_args(d, w);
   aa.ticks = nullptr;
   hipLaunchKernelGGL(k_lazy_adam, dim3(grid), dim3(256), 0, s, lazy_args(d, w, 5), aa);
+  if ((e = ticks_collect(w, 5, s))) return e;
   return (int)hipGetLastError();
 }
 
@@ -1898,7 +1926,9 @@ static int lazy_flush(const anirec_train_desc *d, const TrainWs &w, hipStream_t 
     hipLaunchKernelGGL((k_lazy_flush<true>), dim3(adam_grid(d)), dim3(256), 0, s, lazy_args(d, w, 6));
   else
     hipLaunchKernelGGL((k_lazy_flush<false>), dim3(adam_grid(d)), dim3(256), 0, s, lazy_args(d, w, 6));
+  if (int te = ticks_collect(w, 6, s)) return te;
   hipLaunchKernelGGL(k_lazy_reduce, dim3(1), dim3(1024), 0, s, lazy_args(d, w, 7));
+  if (int te = ticks_collect(w, 7, s)) return te;
   return (int)hipGetLastError();
 }
 
@@ -2001,38 +2031,25 @@ int anirec_train_adam(const anirec_train_desc *d, void *stream) {
 }
 
 // Measurement hook (bench.py).  While armed, every training kernel launched through this library stamps the
-// constant-clock (100 MHz) time of each workgroup's first and last instruction into the workspace; this call
-// synchronises the stream, returns per kernel (0 fwd, 1 head, 2 bwd, 3 adam, 4 lazy catch-up, 5 lazy adam, 6 lazy
-// flush, 7 lazy reduce) max(end) - min(start) over
-// the workgroups of the launches made since the last call [us; -1 = not launched], clears the stamps and arms
-// (enable != 0) or disarms.  Call it once per step: the stamps of two launches of one kernel would merge.
-int anirec_train_stage_ticks(const anirec_train_desc *d, int32_t enable, float *us8_host, void *stream) {
+// constant-clock (100 MHz) time of each workgroup's first and last instruction into the workspace, and the launch
+// function waits for it and adds max(end) - min(start) over its workgroups to the kernel's sum.  This call returns,
+// per kernel (0 fwd, 1 head, 2 bwd, 3 adam, 4 lazy catch-up, 5 lazy adam, 6 lazy flush, 7 lazy reduce), the MEAN
+// duration [us] of the launches made since the last call (-1 = none) and their number, then arms (enable != 0) or
+// disarms.  Armed steps run eagerly (never from the captured graph) and synchronise after every launch.
+int anirec_train_stage_ticks(const anirec_train_desc *d, int32_t enable, float *us8_host, int32_t *launches8_host,
+                             void *stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   TrainWs w = carve(d->workspace, d->max_batch, d->arena_steps);
-  const size_t n = (size_t)8 * 2 * ANIREC_ADAM_BLOCKS;
-  if (us8_host) {
-    unsigned long long *h = new (std::nothrow) unsigned long long[n];
-    if (!h) return ANIREC_EINVAL;
-    hipError_t e = hipStreamSynchronize(s);
-    if (e == hipSuccess) e = hipMemcpy(h, w.ticks, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) {
-      delete[] h;
-      return (int)e;
-    }
-    for (int k = 0; k < 8; ++k) {
-      unsigned long long lo = ~0ull, hi = 0ull;
-      for (int b = 0; b < ANIREC_ADAM_BLOCKS; ++b) {
-        const unsigned long long t0 = h[((size_t)k * ANIREC_ADAM_BLOCKS + b) * 2], t1 = h[((size_t)k * ANIREC_ADAM_BLOCKS + b) * 2 + 1];
-        if (t0 != 0ull && t0 < lo) lo = t0;
-        if (t1 > hi) hi = t1;
-      }
-      us8_host[k] = hi > 0ull && lo != ~0ull && hi >= lo ? (float)((double)(hi - lo) * 0.01) : -1.0f;
-    }
-    delete[] h;
+  for (int k = 0; k < 8; ++k) {
+    if (us8_host) us8_host[k] = g_tick_launches[k] ? (float)(g_tick_sum_us[k] / g_tick_launches[k]) : -1.0f;
+    if (launches8_host) launches8_host[k] = g_tick_launches[k];
+    g_tick_sum_us[k] = 0.0;
+    g_tick_launches[k] = 0;
   }
-  ANIREC_HIP_CHECK(hipMemsetAsync(w.ticks, 0, n * sizeof(unsigned long long), s));
+  ANIREC_HIP_CHECK(hipStreamSynchronize(s));
+  ANIREC_HIP_CHECK(hipMemsetAsync(w.ticks, 0, sizeof(unsigned long long) * 8 * 2 * ANIREC_ADAM_BLOCKS, s));
   g_ticks_on = enable != 0;
   return ANIREC_OK;
 }

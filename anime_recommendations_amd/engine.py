@@ -235,14 +235,20 @@ class TrainEngine:
         _lib.check(self.lib.anirec_train_adam_part(C.byref(self.desc), 2, self._sp()), "anirec_train_adam_part")
 
     def stage_ticks(self, enable=True, read=True):
-        """Measurement hook (bench.py): in-kernel constant-clock stamps.  Returns {"fwd", "head", "bwd", "adam", "lazy_*"} ->
-        duration [us] of the launches made since the last call (None = not launched), clears the stamps and arms /
-        disarms.  Synchronises."""
+        """Measurement hook (bench.py): in-kernel constant-clock stamps.  Returns {"fwd", "head", "bwd", "adam",
+        "lazy_catchup", "lazy_adam", "lazy_flush", "lazy_reduce"} -> mean duration [us] of the launches made since the
+        last call (None = not launched) and, under "launches", their counts; then arms / disarms.  Armed steps run
+        eagerly and synchronise after every launch."""
         us = (C.c_float * 8)()
-        _lib.check(self.lib.anirec_train_stage_ticks(C.byref(self.desc), int(bool(enable)), us if read else None,
-                                                     self._sp()), "anirec_train_stage_ticks")
+        nl = (C.c_int32 * 8)()
+        _lib.check(self.lib.anirec_train_stage_ticks(C.byref(self.desc), int(bool(enable)), us, nl, self._sp()),
+                   "anirec_train_stage_ticks")
+        if not read:
+            return None
         names = ("fwd", "head", "bwd", "adam", "lazy_catchup", "lazy_adam", "lazy_flush", "lazy_reduce")
-        return {k: (float(us[i]) if us[i] >= 0 else None) for i, k in enumerate(names)} if read else None
+        out = {k: (float(us[i]) if nl[i] else None) for i, k in enumerate(names)}
+        out["launches"] = {k: int(nl[i]) for i, k in enumerate(names)}
+        return out
 
     # ---- multi-GPU step halves: one C call each, the collectives go between them ------------
     def _get_stepper(self):

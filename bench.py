@@ -90,7 +90,7 @@ def run_single(workload, steps, warmup, batch, use_graph=True, cpu_baseline=True
     from anime_recommendations_amd.engine import TrainEngine
     n_users, n_anime = WORKLOADS[workload]
     dev = torch.device("cuda:0")
-    total_steps = warmup + steps + 80         # timed region + instrumented per-kernel pass
+    total_steps = warmup + steps + 64         # timed region + instrumented per-kernel passes
     ui, ai, t = synth_ratings(n_users, n_anime, total_steps * batch, dev)
     U, A = init_tables(n_users, n_anime, dev)
     eng = TrainEngine(n_users, n_anime, max_batch=batch, arena_steps=64)
@@ -111,18 +111,32 @@ def run_single(workload, steps, warmup, batch, use_graph=True, cpu_baseline=True
     assert int(rec["step_fwd"]) == warmup + steps and np.isfinite(rec["last_loss"])
 
     # instrumented pass: the SAME step sequence continued eagerly, every kernel stamping the constant-clock time of each
-    # workgroup's first and last instruction (anirec_train_stage_ticks): a kernel's duration is max(end) - min(start),
+    # workgroup's first and last instruction (anirec_train_stage_ticks): a launch's duration is max(end) - min(start),
     # taken in the step, on the batch the step really reads, behind whatever the previous kernel left in the caches
     # (round 2 replayed one batch 50 x: its gathered rows were cache-resident from the second repetition on).
-    # The dominant kernel is ALSO timed by HIP events on the engine's stream (the roofline figure): the host is far
-    # ahead of a 190 us kernel, so the pair brackets the kernel and nothing else.
-    kern = {"fwd": [], "head": [], "bwd": [], "adam_by_stamps": []}
     first = warmup + steps
+    lazy_ms = None
+    n_lazy = 0
     eng.stage_ticks(True, read=False)
+    if eng.lazy:          # the path the timed region ran: 32 steps = four 8-step windows
+        n_lazy = 32
+        eng.run(n_lazy, use_graph=False, first_step=first)
+        tk = eng.stage_ticks(True)
+        lazy_ms = {k: tk[k] * 1e-3 for k in ("lazy_catchup", "fwd", "head", "bwd", "lazy_adam", "lazy_flush", "lazy_reduce")}
+        lazy_ms["launches"] = {k: tk["launches"][k] for k in ("lazy_catchup", "lazy_adam", "lazy_flush", "lazy_reduce")}
+    # the dense kernels, stage by stage, by the same stamps ...
+    for k in range(8):
+        eng.prep(first + n_lazy + k, 1)
+        eng.fwd()
+        eng.head()
+        eng.bwd()
+        eng.adam()
+    tk = eng.stage_ticks(False)
+    # ... and the dense Adam by HIP events on the engine's stream (the roofline contract), stamps OFF: the host is far
+    # ahead of a 190 us kernel, so the event pair brackets the kernel and nothing else
     evs = []
-    n_inst = max(8, min(64, steps // 2))
-    for k in range(n_inst):
-        eng.prep(first + k, 1)
+    for k in range(16):
+        eng.prep(first + n_lazy + 8 + k, 1)
         eng.fwd()
         eng.head()
         eng.bwd()
@@ -132,44 +146,63 @@ def run_single(workload, steps, warmup, batch, use_graph=True, cpu_baseline=True
         eng.adam()
         e1.record(eng.stream)
         evs.append((e0, e1))
-        tk = eng.stage_ticks(True)
-        for name in ("fwd", "head", "bwd"):
-            kern[name].append(tk[name])
-        kern["adam_by_stamps"].append(tk["adam"])
-    eng.stage_ticks(False, read=False)
     eng.synchronize()
-    kern_ms = {k: float(np.mean(v)) * 1e-3 for k, v in kern.items()}
+    kern_ms = {k: tk[k] * 1e-3 for k in ("fwd", "head", "bwd")}
+    kern_ms["adam_by_stamps"] = tk["adam"] * 1e-3
     kern_ms["adam"] = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     rows = n_users + n_anime
     adam_bytes = ADAM_BYTES_PER_ELEM * rows * 128
     adam_gbs = adam_bytes / (kern_ms["adam"] * 1e-3) / 1e9
-    # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (PMC cannot be collected
-    # from inside this process); quoted only for the workload it was measured on AND only while the kernel source
-    # is still the one that was measured (git blob hash recorded next to the counters)
-    traffic = None
-    if workload == "s109m" and batch == 10_000:
-        traffic = pmc_traffic("train_s109m", "k_adam<true>", source="anirec_train.hip")
-    elif workload == "s7m" and batch == 10_000:      # cache-resident tables: the plain (not non-temporal) kernel
-        traffic = pmc_traffic("train_s7m", "k_adam<false>", source="anirec_train.hip")
+    # HBM traffic from the PMC passes committed under profiles/ (PMC cannot be collected from inside this process);
+    # quoted only for the workload it was measured on AND only while the kernel source is still the one that was
+    # measured (git blob hash recorded next to the counters)
+    tag = {"s109m": "train_s109m", "s7m": "train_s7m"}.get(workload) if batch == 10_000 else None
+    dense_name = "k_adam<true>" if rows * 128 * 4 * 3 > (192 << 20) else "k_adam<false>"
+    dense_roof = {"kernel": "k_adam (dense fused Adam, both tables: one step per launch)", "bound": "hbm",
+                  "achieved": adam_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": adam_gbs / HBM_PEAK_GBS,
+                  "traffic": pmc_traffic(tag, dense_name, source="anirec_train.hip") if tag else None,
+                  "algorithmic_bytes_per_launch": adam_bytes, "avg_launch_ms": kern_ms["adam"]}
     step_bytes = (FWD_BYTES_PER_RATING + BWD_BYTES_PER_RATING) * batch + adam_bytes
+    step_ms = dt / steps * 1e3
     out = {
         "value": steps * batch / dt,
-        "ms_per_step": dt / steps * 1e3,
+        "ms_per_step": step_ms,
         "loss": float(rec["last_loss"]),
+        "adam": "lazy" if eng.lazy else "dense",
         "kernels_ms": kern_ms,
-        "roofline": {"kernel": "k_adam (dense fused Adam, both tables)", "bound": "hbm",
-                     "achieved": adam_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": adam_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": adam_bytes,
-                     "avg_launch_ms": kern_ms["adam"]},
         # whole-step roofline of SURVEY.md §8(d): (3.1 KB x B + 28 B x table elements) / step time
         "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_step": step_bytes,
                           "achieved": step_bytes / (dt / steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS,
-                          "sum_of_kernels_ms": kern_ms["fwd"] + kern_ms["head"] + kern_ms["bwd"] + kern_ms["adam"]},
+                          "frac": step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS},
         "fwd_gbs": FWD_BYTES_PER_RATING * batch / (kern_ms["fwd"] * 1e-3) / 1e9,
         "bwd_gbs": BWD_BYTES_PER_RATING * batch / (kern_ms["bwd"] * 1e-3) / 1e9,
     }
+    if eng.lazy:
+        # the dominant kernel of the lazy path: ONE pass over W, M, V applies every row's pending steps of an 8-step
+        # window.  `achieved` is on the ALGORITHMIC bytes of SURVEY §8(d) — 28 B per element per step, i.e. what the
+        # dense update it replaces moves for those steps — so frac > 1 says how far under the dense algorithm's
+        # traffic the window runs; `moved_*` is what the pass really reads + writes (W, M, V once: 24 B per element).
+        win = lazy_ms["launches"]["lazy_adam"] / max(1, lazy_ms["launches"]["lazy_flush"])
+        fl_ms = lazy_ms["lazy_flush"]
+        alg = adam_bytes * win
+        moved = 24 * rows * 128
+        out["lazy_kernels_ms"] = lazy_ms
+        out["roofline"] = {"kernel": "k_lazy_flush (lazy dense Adam: every row's pending steps of a %d-step window in one "
+                                     "pass over W, M, V; IEEE sqrt + divide per element-step: VALU-bound)" % round(win),
+                           "bound": "hbm", "achieved": alg / (fl_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": alg / (fl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "traffic": pmc_traffic(tag, "k_lazy_flush<true>" if dense_name == "k_adam<true>" else "k_lazy_flush<false>",
+                                                  source="anirec_train.hip") if tag else None,
+                           "algorithmic_bytes_per_launch": alg, "avg_launch_ms": fl_ms, "steps_per_launch": win,
+                           "moved_bytes_per_launch": moved, "moved_gbs": moved / (fl_ms * 1e-3) / 1e9,
+                           "moved_frac": moved / (fl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        per_step = (lazy_ms["lazy_catchup"] + lazy_ms["fwd"] + lazy_ms["head"] + lazy_ms["bwd"] + lazy_ms["lazy_adam"]
+                    + (fl_ms + lazy_ms["lazy_reduce"]) / win)
+        out["step_roofline"]["sum_of_kernels_ms"] = per_step
+        out["dense_kernel_roofline"] = dense_roof
+    else:
+        out["roofline"] = dense_roof
+        out["step_roofline"]["sum_of_kernels_ms"] = kern_ms["fwd"] + kern_ms["head"] + kern_ms["bwd"] + kern_ms["adam"]
     eng.close()
     del eng
     torch.cuda.empty_cache()
@@ -727,16 +760,20 @@ def main():
         "roofline": res["roofline"],
         "step_roofline": res["step_roofline"],
         "cpu_baseline": res.get("cpu_baseline"),
+        "adam": res["adam"],
         "kernels_ms": res["kernels_ms"],
         "embed_fwd_GBps": res["fwd_gbs"], "embed_bwd_GBps": res["bwd_gbs"],
         "final_loss": res["loss"],
     }
+    for k in ("lazy_kernels_ms", "dense_kernel_roofline"):
+        if k in res:
+            line[k] = res[k]
     if not args.no_also:
         other = "s7m" if args.workload == "s109m" else "s109m"
         r2 = run_single(other, args.steps, args.warmup, args.batch, use_graph=not args.no_graph,
                         cpu_baseline=not args.no_cpu_baseline)
         line["also"] = {}
-        shape_rec = {"value": r2["value"], "unit": "ratings/s", "ms_per_step": r2["ms_per_step"],
+        shape_rec = {"value": r2["value"], "unit": "ratings/s", "ms_per_step": r2["ms_per_step"], "adam": r2["adam"],
                      "roofline": r2["roofline"], "step_roofline": r2["step_roofline"], "kernels_ms": r2["kernels_ms"],
                      "cpu_baseline": r2.get("cpu_baseline"),
                      "what": "%d steps on the %s table shape, i.i.d. synthetic batches resident in HBM" % (args.steps, other)}

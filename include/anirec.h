@@ -170,10 +170,12 @@ int anirec_train_head(const anirec_train_desc *d, void *stream);
 int anirec_train_bwd(const anirec_train_desc *d, void *stream);
 int anirec_train_adam(const anirec_train_desc *d, void *stream);
 /* Measurement hook (bench.py): while armed, the training kernels stamp each workgroup's first / last instruction
- * with the 100 MHz constant clock.  Synchronises the stream, writes to us4_host (may be NULL) the duration [us] of
- * kernel 0 fwd, 1 head, 2 bwd, 3 adam over the launches since the last call (-1 = none),
- * clears the stamps, then arms (enable != 0) or disarms.  Armed steps never replay the captured graph. */
-int anirec_train_stage_ticks(const anirec_train_desc *d, int32_t enable, float *us4_host, void *stream);
+ * with the 100 MHz constant clock and every launch is followed by a synchronisation that turns the stamps into one
+ * duration.  Returns per kernel — 0 fwd, 1 head, 2 bwd, 3 adam, 4 lazy catch-up, 5 lazy adam, 6 lazy flush, 7 lazy
+ * reduce — the mean duration [us] of the launches since the last call (-1 = none) and their count (either pointer
+ * may be NULL), then arms (enable != 0) or disarms.  Armed steps never replay the captured graph. */
+int anirec_train_stage_ticks(const anirec_train_desc *d, int32_t enable, float *us8_host, int32_t *launches8_host,
+                             void *stream);
 
 /* adam as two launches (dense_mode 1): which == 1 updates the user rows (may run while the anime gradient is
  * still in the all-reduce), which == 2 the anime rows and finishes the step. */
