@@ -13,18 +13,18 @@ pytestmark = pytest.mark.gpu
 N_USERS, N_ANIME, B = 350_000, 18_000, 10_000
 
 
-def _train(steps, seed=1):
+def _train(steps, seed=1, lazy=None, use_graph=False, arena=8):
     import bench
     from anime_recommendations_amd.engine import TrainEngine
     from anime_recommendations_amd import schedule
     dev = torch.device("cuda:0")
     ui, ai, t = bench.synth_ratings(N_USERS, N_ANIME, steps * B, dev, seed=seed)
     U, A = bench.init_tables(N_USERS, N_ANIME, dev)
-    eng = TrainEngine(N_USERS, N_ANIME, max_batch=B, arena_steps=8)
+    eng = TrainEngine(N_USERS, N_ANIME, max_batch=B, arena_steps=arena, lazy=lazy)
     eng.set_head(w=1.2)
     eng.set_weights(U, A)
     eng.set_epoch(ui, ai, t, np.arange(steps) * B, np.full(steps, B), schedule.adam_alphas(1e-5, 1, steps))
-    eng.run(steps, use_graph=False)
+    eng.run(steps, use_graph=use_graph)
     eng.synchronize()
     return eng, U.cpu().numpy(), ui.cpu().numpy()
 
@@ -47,6 +47,24 @@ def test_s109m_shape_training_is_deterministic_and_untouched_rows_are_bit_exact(
     for step in range(3):
         orc.adam_update(w, m, v, np.float32(2e-4) * w, orc.adam_alpha(1e-5, step + 1))
     assert (W1[untouched] == w).all() and (M1[untouched] == m).all() and (V1[untouched] == v).all()
+
+
+def test_s109m_shape_lazy_adam_equals_dense_adam_bitwise():
+    """BASELINE configs[2] table shape, 43 steps through the captured graph (five 8-step windows + an eager tail of
+    three): the lazy dense Adam — the default at this size — leaves bit for bit the tables and Adam moments of the
+    dense kernel (368 000 rows x 128, every element), the same scalar state, and a History loss within the rounding
+    of its L2 sum."""
+    dense, _, _ = _train(43, seed=5, lazy=False, use_graph=True, arena=32)
+    lazy, _, _ = _train(43, seed=5, lazy=None, use_graph=True, arena=32)
+    assert lazy.lazy and not dense.lazy
+    assert torch.equal(dense.W, lazy.W) and torch.equal(dense.M, lazy.M) and torch.equal(dense.V, lazy.V)
+    rd, rz = dense.read_state(), lazy.read_state()
+    for k in ("w", "b", "gamma", "beta", "mov_mean", "mov_var", "last_mse", "bce_wsum", "se_sum", "step_fwd"):
+        assert rd[k] == rz[k], k
+    assert abs(float(rd["last_loss"]) - float(rz["last_loss"])) < 3e-6 * abs(float(rd["last_loss"]))
+    assert abs(float(rd["loss_wsum"]) - float(rz["loss_wsum"])) < 3e-6 * abs(float(rd["loss_wsum"]))
+    dense.close()
+    lazy.close()
 
 
 def _train_s7m(steps, use_graph):
