@@ -675,6 +675,7 @@ struct BwdArgs {
   const float *dy, *su, *sa;
   float *P, *S;
   int32_t *rowmap;
+  int32_t *touched;  // lazy dense Adam: [rows], step + 1 for every row the batch touches (or nullptr)
   int arena_steps;
   unsigned long long *ticks;
 };
@@ -812,6 +813,7 @@ __device__ __forceinline__ void bwd_chunk(const BwdArgs &a, const StepPub &pub, 
   if (l == 0) {
     a.S[pc] = ssum;
     if (rec.w > 0 && a.rowmap != nullptr) a.rowmap[(size_t)par * a.rows + rec.x] = ((gc << 10) | (rec.w - 1)) + 1;
+    if (rec.w > 0 && a.touched != nullptr) a.touched[rec.x] = pub.step + 1;
   }
 }
 
@@ -1178,12 +1180,15 @@ constexpr int kLzWin = ANIREC_LAZY_WINDOW;
 
 struct LazyState {
   int32_t *row_step;  // [rows] the step every row has been updated to (rows are current at the window's start)
+  int32_t *mark;      // [rows] t + 1 for the rows batch t touched (written by bwd(t))
   float *rowsq;       // [rows][kLzWin] sum(W_s^2) of the row for the window's steps it has already taken
 };
 __host__ __device__ inline LazyState lazy_carve(void *base, int rows) {
+  const size_t col = (sizeof(int32_t) * (size_t)rows + 255) / 256 * 256;
   LazyState z;
   z.row_step = (int32_t *)base;
-  z.rowsq = (float *)((char *)base + ((sizeof(int32_t) * (size_t)rows + 255) / 256 * 256));
+  z.mark = (int32_t *)((char *)base + col);
+  z.rowsq = (float *)((char *)base + 2 * col);
   return z;
 }
 
@@ -1200,6 +1205,7 @@ struct LazyArgs {
   size_t slot_bytes;
   int cap, capC, arena_steps;
   float *lzpart, *lzring, *regpart;
+  int fuse_nb;  // k_lazy_adam: > 0 = workgroups [fuse_nb, 2 fuse_nb) catch the rows of batch t + 1 up to step t + 1
   unsigned long long *ticks;
 };
 
@@ -1255,8 +1261,8 @@ __device__ __forceinline__ void lazy_alphas(const LazyArgs &a, int w0, int nj, f
 }
 
 // the distinct row a half-wave of the chunk-table grid owns (first chunk of a row's run), or -1
-__device__ __forceinline__ int lazy_chunk_row(const LazyArgs &a, int step, int &gc, int &nch) {
-  const int hw = blockIdx.x * 8 + (threadIdx.x >> 5);
+__device__ __forceinline__ int lazy_chunk_row(const LazyArgs &a, int step, int bid, int &gc, int &nch) {
+  const int hw = bid * 8 + (threadIdx.x >> 5);
   const int T = hw >= a.capC ? 1 : 0;
   const int c = hw - T * a.capC;
   Slot sl = slot_of(a.arena, a.slot_bytes, a.cap, a.capC, step % a.arena_steps);
@@ -1268,40 +1274,43 @@ __device__ __forceinline__ int lazy_chunk_row(const LazyArgs &a, int step, int &
   return rec.x;
 }
 
-// before fwd(t): the rows batch t touches take their pending L2-only steps, so that fwd / bwd read current rows
-__global__ __launch_bounds__(256) void k_lazy_catchup(LazyArgs a) {
-  tick(a.ticks, 0);
-  const int step = a.state->step_fwd;
-  const int w0 = a.w0[0];
+// the rows batch `step` touches take their pending L2-only steps, so that fwd / bwd of that step read current rows.
+// skip_mark > 0: rows whose mark equals it belong to the batch the sparse step of the SAME launch is updating —
+// not ours (that half of the launch brings them to `step` itself)
+__device__ __forceinline__ void lazy_catchup_row(const LazyArgs &a, int step, int w0, int bid, int skip_mark) {
   const int l = threadIdx.x & 31;
   int gc, nch;
-  const int row = lazy_chunk_row(a, step, gc, nch);
-  if (row >= 0) {
-    const int ta = a.z.row_step[row];
-    if (ta < step) {
-      const size_t e = (size_t)row * kRowVec + l;
-      Row3 x;
-      x.w = reinterpret_cast<const float4 *>(a.W)[e];
-      x.m = reinterpret_cast<const float4 *>(a.M)[e];
-      x.v = reinterpret_cast<const float4 *>(a.V)[e];
-      float alpha[kLzWin], sq[kLzWin];
-      lazy_alphas(a, w0, step - w0, alpha);
+  const int row = lazy_chunk_row(a, step, bid, gc, nch);
+  if (row < 0) return;
+  if (skip_mark > 0 && a.z.mark[row] == skip_mark) return;
+  const int ta = a.z.row_step[row];
+  if (ta >= step) return;
+  const size_t e = (size_t)row * kRowVec + l;
+  Row3 x;
+  x.w = reinterpret_cast<const float4 *>(a.W)[e];
+  x.m = reinterpret_cast<const float4 *>(a.M)[e];
+  x.v = reinterpret_cast<const float4 *>(a.V)[e];
+  float alpha[kLzWin], sq[kLzWin];
+  lazy_alphas(a, w0, step - w0, alpha);
 #pragma unroll
-      for (int j = 0; j < kLzWin; ++j) sq[j] = 0.f;
-      lazy_replay(x, ta - w0, step - w0, alpha, a.two_l2, sq);
-      reinterpret_cast<float4 *>(a.W)[e] = x.w;
-      reinterpret_cast<float4 *>(a.M)[e] = x.m;
-      reinterpret_cast<float4 *>(a.V)[e] = x.v;
-      float mine = 0.f;
+  for (int j = 0; j < kLzWin; ++j) sq[j] = 0.f;
+  lazy_replay(x, ta - w0, step - w0, alpha, a.two_l2, sq);
+  reinterpret_cast<float4 *>(a.W)[e] = x.w;
+  reinterpret_cast<float4 *>(a.M)[e] = x.m;
+  reinterpret_cast<float4 *>(a.V)[e] = x.v;
+  float mine = 0.f;
 #pragma unroll
-      for (int j = 0; j < kLzWin; ++j) {
-        const float t = halfwave_sum(sq[j]);
-        if (l == j) mine = t;
-      }
-      if (l >= ta - w0 && l < step - w0) a.z.rowsq[(size_t)row * kLzWin + l] = mine;
-      if (l == 0) a.z.row_step[row] = step;
-    }
+  for (int j = 0; j < kLzWin; ++j) {
+    const float t = halfwave_sum(sq[j]);
+    if (l == j) mine = t;
   }
+  if (l >= ta - w0 && l < step - w0) a.z.rowsq[(size_t)row * kLzWin + l] = mine;
+  if (l == 0) a.z.row_step[row] = step;
+}
+
+__global__ __launch_bounds__(256) void k_lazy_catchup(LazyArgs a) {
+  tick(a.ticks, 0);
+  lazy_catchup_row(a, a.state->step_fwd, a.w0[0], blockIdx.x, 0);
   tick(a.ticks, 1);
 }
 
@@ -1315,8 +1324,17 @@ __global__ __launch_bounds__(256) void k_lazy_adam(LazyArgs a, AdamArgs d) {
   const int w0 = a.w0[0];
   const float alpha = d.pub[par].alpha;
   const int l = threadIdx.x & 31;
+  if (a.fuse_nb > 0 && (int)blockIdx.x >= a.fuse_nb) {
+    // second half of the grid: the rows of batch t + 1 that batch t does NOT touch (bwd(t) marked its rows) are
+    // caught up to step t + 1 here, beside the sparse step — disjoint rows, so no order between the halves matters
+    // — and the next step starts at fwd.  (Step t itself is an L2-only step for them.)
+    if (step + 1 < a.n_steps && step + 1 - w0 <= kLzWin)
+      lazy_catchup_row(a, step + 1, w0, (int)blockIdx.x - a.fuse_nb, step + 1);
+    tick(a.ticks, 1);
+    return;
+  }
   int gc, nch;
-  const int row = lazy_chunk_row(a, step, gc, nch);
+  const int row = lazy_chunk_row(a, step, (int)blockIdx.x, gc, nch);
   if (row >= 0) {
     const size_t e = (size_t)row * kRowVec + l;
     const float4 *P4 = reinterpret_cast<const float4 *>(d.P) + (size_t)par * 2 * d.capC * kRowVec;
@@ -1776,6 +1794,7 @@ static BwdArgs bwd_args(const anirec_train_desc *d, const TrainWs &w) {
   a.P = w.P;
   a.S = w.S;
   a.rowmap = d->rowmap;
+  a.touched = nullptr;
   a.arena_steps = w.arena_steps;
   a.ticks = ticks_of(w, 2);
   return a;
@@ -1783,7 +1802,10 @@ static BwdArgs bwd_args(const anirec_train_desc *d, const TrainWs &w) {
 
 static int launch_bwd_only(const anirec_train_desc *d, const TrainWs &w, hipStream_t s, bool lazy = false) {
   BwdArgs a = bwd_args(d, w);
-  if (lazy) a.rowmap = nullptr;  // the lazy update walks the chunk table itself: no row map to fill (or to clear)
+  if (lazy) {  // the lazy update walks the chunk table itself: no row map to fill (or to clear), but a mark per row
+    a.rowmap = nullptr;
+    a.touched = lazy_carve(d->lazy_state, table_rows(d)).mark;
+  }
   hipLaunchKernelGGL(k_bwd, dim3((2 * w.capC + 7) / 8), dim3(256), 0, s, a);
   if (int te = ticks_collect(w, 2, s)) return te;
   return (int)hipGetLastError();
@@ -1894,6 +1916,7 @@ static LazyArgs lazy_args(const anirec_train_desc *d, const TrainWs &w, int tick
   a.lzpart = w.lzpart;
   a.lzring = w.lzring;
   a.regpart = w.regpart;
+  a.fuse_nb = 0;
   a.ticks = ticks_of(w, ticks_slot);
   return a;
 }
@@ -1902,21 +1925,29 @@ static LazyArgs lazy_args(const anirec_train_desc *d, const TrainWs &w, int tick
 static int lazy_begin(const anirec_train_desc *d, const TrainWs &w, int first_step, hipStream_t s) {
   const LazyState z = lazy_carve(d->lazy_state, table_rows(d));
   ANIREC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)z.row_step, first_step, (size_t)table_rows(d), s));
+  ANIREC_HIP_CHECK(hipMemsetAsync(z.mark, 0, sizeof(int32_t) * (size_t)table_rows(d), s));  // (marks of an earlier schedule)
   ANIREC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(w.sel + 1), first_step, 1, s));
   return ANIREC_OK;
 }
 
-static int lazy_step(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
+// catchup_first: the rows of this step's batch are not known to be current (first step of a run or of a prepared
+// block): a stand-alone catch-up launch.  fuse_next: the NEXT step's batch is already in the prep arena, so the sparse
+// launch also catches its rows up (second half of its grid) and the next step needs no catch-up launch.
+static int lazy_step(const anirec_train_desc *d, const TrainWs &w, hipStream_t s, bool catchup_first, bool fuse_next) {
   const int grid = (2 * w.capC + 7) / 8;
-  hipLaunchKernelGGL(k_lazy_catchup, dim3(grid), dim3(256), 0, s, lazy_args(d, w, 4));
   int e;
-  if ((e = ticks_collect(w, 4, s))) return e;
+  if (catchup_first) {
+    hipLaunchKernelGGL(k_lazy_catchup, dim3(grid), dim3(256), 0, s, lazy_args(d, w, 4));
+    if ((e = ticks_collect(w, 4, s))) return e;
+  }
   if ((e = launch_fwd(d, w, s))) return e;
   if ((e = launch_head(d, w, s))) return e;
   if ((e = launch_bwd_only(d, w, s, true))) return e;
   AdamArgs aa = adam_args(d, w);
   aa.ticks = nullptr;
-  hipLaunchKernelGGL(k_lazy_adam, dim3(grid), dim3(256), 0, s, lazy_args(d, w, 5), aa);
+  LazyArgs la = lazy_args(d, w, 5);
+  la.fuse_nb = fuse_next ? grid : 0;
+  hipLaunchKernelGGL(k_lazy_adam, dim3(fuse_next ? 2 * grid : grid), dim3(256), 0, s, la, aa);
   if ((e = ticks_collect(w, 5, s))) return e;
   return (int)hipGetLastError();
 }
@@ -1943,7 +1974,7 @@ size_t anirec_packet_floats(int32_t max_batch) { return 2 * (size_t)packet_cap(m
 
 size_t anirec_train_lazy_bytes(int32_t rows) {
   if (rows < 1) return 0;
-  return (sizeof(int32_t) * (size_t)rows + 255) / 256 * 256 + sizeof(float) * (size_t)rows * ANIREC_LAZY_WINDOW;
+  return 2 * ((sizeof(int32_t) * (size_t)rows + 255) / 256 * 256) + sizeof(float) * (size_t)rows * ANIREC_LAZY_WINDOW;
 }
 
 size_t anirec_train_workspace_bytes(int32_t max_batch, int32_t arena_steps) {
@@ -2364,8 +2395,8 @@ static int front_of_step(anirec_trainer *t, hipStream_t s) {
   return launch_bwd_only(&t->d, t->ws, s);
 }
 
-static int one_step(anirec_trainer *t, hipStream_t s) {
-  if (lazy_on(&t->d)) return lazy_step(&t->d, t->ws, s);
+static int one_step(anirec_trainer *t, hipStream_t s, bool catchup_first = true, bool fuse_next = false) {
+  if (lazy_on(&t->d)) return lazy_step(&t->d, t->ws, s, catchup_first, fuse_next);
   int e;
   if ((e = front_of_step(t, s))) return e;
   return launch_adam(&t->d, t->ws, s);
@@ -2401,7 +2432,9 @@ int anirec_trainer_run(anirec_trainer *t, int32_t first_step, int32_t n_steps, i
       const bool lazy = lazy_on(&t->d);
       int e = launch_prep(&t->d, t->ws, G, G, true, s);  // steps cursor+G .. cursor+2G
       for (int i = 0; i < G && !e; ++i) {
-        e = one_step(t, s);
+        // lazy: the batches of the whole block (and of the next one) are in the arena: every sparse launch but the
+        // last also catches the next batch's rows up; only the block's first step needs a catch-up launch of its own
+        e = one_step(t, s, i == 0, i + 1 < G);
         // lazy: a flush every kLzWin steps and at the end of the block (a replay leaves the tables up to date)
         if (!e && lazy && ((i + 1) % kLzWin == 0 || i + 1 == G)) e = lazy_flush(&t->d, t->ws, s);
       }
@@ -2434,7 +2467,7 @@ int anirec_trainer_run(anirec_trainer *t, int32_t first_step, int32_t n_steps, i
       if (e) return e;
     }
     for (int i = 0; i < blk; ++i) {
-      int e = one_step(t, s);
+      int e = one_step(t, s, i == 0, i + 1 < blk);  // (within a prepared block the next batch's tables exist)
       if (e) return e;
       if (lazy && (++open == kLzWin || (i + 1 == blk && done + blk >= n_steps))) {
         if ((e = lazy_flush(&t->d, t->ws, s))) return e;
