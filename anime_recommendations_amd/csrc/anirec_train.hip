@@ -1224,35 +1224,136 @@ __device__ __forceinline__ float l2_only_grad(float w, float two_l2) {
   return two_l2 * w + 0.0f;
 }
 
-__device__ __forceinline__ void lazy_one_step(Row3 &x, float alpha, float two_l2, float &sq) {
+// ---- the replayed Adam step on packed pairs -----------------------------------------------------------------
+// The flush is bound by its arithmetic: the compiler's correctly rounded sqrtf (15 instructions: scaling for tiny
+// inputs, v_sqrt_f32, two +-1 ulp residual tests, class fix-up) and IEEE divide (11: v_div_scale x2, v_rcp_f32, the
+// Markstein fma chain, v_div_fmas, v_div_fixup) per element-step, all scalar.  For operands in the exponent range
+// Adam's moments live in, the scaling and fix-up steps are identities, and what is left — the residual tests and the
+// fma chain, instruction for instruction what the expansions execute — runs on PAIRS (v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32).  A wave whose operands leave the range (a moment decayed to a denormal, an exact zero) takes the
+// compiler's path for that step: the results are the dense kernel's bit for bit either way (tested on every element
+// of the S109M tables).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// correctly rounded sqrt of x in [2^-96, 2^96]: v_sqrt_f32 is within 1 ulp; the residuals pick the neighbour
+__device__ __forceinline__ f32x2 sqrt_pair_normal(f32x2 x) {
+  f32x2 s, sm, sp;
+  s.x = __builtin_amdgcn_sqrtf(x.x);
+  s.y = __builtin_amdgcn_sqrtf(x.y);
+  sm.x = __uint_as_float(__float_as_uint(s.x) - 1u);
+  sm.y = __uint_as_float(__float_as_uint(s.y) - 1u);
+  sp.x = __uint_as_float(__float_as_uint(s.x) + 1u);
+  sp.y = __uint_as_float(__float_as_uint(s.y) + 1u);
+  const f32x2 r1 = pk_fma(-sm, s, x), r2 = pk_fma(-sp, s, x);
+  f32x2 res;
+  res.x = 0.f >= r1.x ? sm.x : s.x;
+  res.y = 0.f >= r1.y ? sm.y : s.y;
+  res.x = 0.f < r2.x ? sp.x : res.x;
+  res.y = 0.f < r2.y ? sp.y : res.y;
+  return res;
+}
+
+// correctly rounded n / d for operands that need no v_div_scale scaling and no v_div_fixup
+__device__ __forceinline__ f32x2 div_pair_normal(f32x2 n, f32x2 d) {
+#pragma clang fp contract(off)
+  f32x2 y0;
+  y0.x = __builtin_amdgcn_rcpf(d.x);
+  y0.y = __builtin_amdgcn_rcpf(d.y);
+  const f32x2 one = {1.0f, 1.0f};
+  const f32x2 e = pk_fma(-d, y0, one);
+  const f32x2 y = pk_fma(e, y0, y0);
+  const f32x2 q0 = n * y;
+  const f32x2 r0 = pk_fma(-d, q0, n);
+  const f32x2 q1 = pk_fma(r0, y, q0);
+  const f32x2 r1 = pk_fma(-d, q1, n);
+  return pk_fma(r1, y, q1);
+}
+
+__device__ __forceinline__ bool in_range(float x, float lo, float hi) { return x >= lo && x <= hi; }
+
+// one L2-only Adam step of a pair by the short sequences; returns whether every operand was inside the range they
+// are exact for (the caller discards the whole replay of the wave otherwise)
+__device__ __forceinline__ bool adam_pair_l2(f32x2 &w, f32x2 &m, f32x2 &v, float alpha, float two_l2) {
+#pragma clang fp contract(off)
+  const f32x2 g = two_l2 * w + 0.0f;
+  const f32x2 mn = m + (g - m) * kOneMinusB1;
+  const f32x2 vn = v + (g * g - v) * kOneMinusB2;
+  const f32x2 num = mn * alpha;
+  constexpr float kLo = 0x1p-60f, kHi = 0x1p60f;
+  const bool ok = in_range(vn.x, 0x1p-96f, 0x1p96f) && in_range(vn.y, 0x1p-96f, 0x1p96f) &&
+                  in_range(fabsf(num.x), kLo, kHi) && in_range(fabsf(num.y), kLo, kHi);
+  const f32x2 den = sqrt_pair_normal(vn) + kAdamEps;  // in [1e-7, 2^48 + eps]: inside the divide's range
+  w = w - div_pair_normal(num, den);
+  m = mn;
+  v = vn;
+  return ok;
+}
+
+template <bool kFast>
+__device__ __forceinline__ bool lazy_one_step(Row3 &x, float alpha, float two_l2, float &sq) {
   sq = x.w.x * x.w.x + x.w.y * x.w.y + x.w.z * x.w.z + x.w.w * x.w.w;
+  if (kFast) {
+    f32x2 w0 = {x.w.x, x.w.y}, w1 = {x.w.z, x.w.w}, m0 = {x.m.x, x.m.y}, m1 = {x.m.z, x.m.w}, v0 = {x.v.x, x.v.y},
+          v1 = {x.v.z, x.v.w};
+    const bool f0 = adam_pair_l2(w0, m0, v0, alpha, two_l2);
+    const bool f1 = adam_pair_l2(w1, m1, v1, alpha, two_l2);
+    x.w = make_float4(w0.x, w0.y, w1.x, w1.y);
+    x.m = make_float4(m0.x, m0.y, m1.x, m1.y);
+    x.v = make_float4(v0.x, v0.y, v1.x, v1.y);
+    return f0 && f1;
+  }
+  // the compiler's full expansions (scaling, fix-up)
   const float gx = l2_only_grad(x.w.x, two_l2), gy = l2_only_grad(x.w.y, two_l2), gz = l2_only_grad(x.w.z, two_l2),
               gw = l2_only_grad(x.w.w, two_l2);
   adam_elem(x.w.x, x.m.x, x.v.x, gx, alpha);
   adam_elem(x.w.y, x.m.y, x.v.y, gy, alpha);
   adam_elem(x.w.z, x.m.z, x.v.z, gz, alpha);
   adam_elem(x.w.w, x.m.w, x.v.w, gw, alpha);
+  return true;
 }
 
-__device__ __forceinline__ void lazy_replay(Row3 &x, int j0, int j1, const float (&alpha)[kLzWin], float two_l2,
-                                            float (&sq)[kLzWin]) {
+template <bool kFast>
+__device__ __forceinline__ bool lazy_replay_path(Row3 &x, int j0, int j1, const float (&alpha)[kLzWin], float two_l2,
+                                                 float (&sq)[kLzWin]) {
+  bool ok = true;
   if (__all(j0 <= 0 && j1 >= kLzWin)) {  // the common case (a row untouched for a whole window): no predication
 #pragma unroll
-    for (int j = 0; j < kLzWin; ++j) lazy_one_step(x, alpha[j], two_l2, sq[j]);
-    return;
+    for (int j = 0; j < kLzWin; ++j) ok &= lazy_one_step<kFast>(x, alpha[j], two_l2, sq[j]);
+    return ok;
   }
 #pragma unroll
   for (int j = 0; j < kLzWin; ++j) {
     if (__any(j >= j0 && j < j1)) {  // wave-uniform skip, then per-lane selection of the stepped values
       Row3 y = x;
       float q;
-      lazy_one_step(y, alpha[j], two_l2, q);
+      const bool o = lazy_one_step<kFast>(y, alpha[j], two_l2, q);
       if (j >= j0 && j < j1) {
         x = y;
         sq[j] = q;
+        ok &= o;
       }
     }
   }
+  return ok;
+}
+
+// pending pure-L2 steps [j0, j1) (window-relative) of one row, a float4 per lane; sq[j] receives this lane's part of
+// sum(W_s^2), the weights step s READ.  The packed short sequences first; if any lane of the wave met an operand
+// outside their range, the whole replay is redone from the saved row with the compiler's expansions (rare: a moment
+// decayed to a denormal, an exact zero) — kept as a separate block so that the two never share registers.
+// (the row is re-read from memory for the redo — nothing has been stored yet — rather than kept in 12 more registers)
+__device__ __forceinline__ void lazy_replay(Row3 &x, int j0, int j1, const float (&alpha)[kLzWin], float two_l2,
+                                            float (&sq)[kLzWin], const float *W, const float *M, const float *V,
+                                            size_t e) {
+  if (__all(lazy_replay_path<true>(x, j0, j1, alpha, two_l2, sq))) return;
+  x.w = reinterpret_cast<const float4 *>(W)[e];
+  x.m = reinterpret_cast<const float4 *>(M)[e];
+  x.v = reinterpret_cast<const float4 *>(V)[e];
+#pragma unroll
+  for (int j = 0; j < kLzWin; ++j) sq[j] = 0.f;
+  (void)lazy_replay_path<false>(x, j0, j1, alpha, two_l2, sq);
 }
 
 __device__ __forceinline__ void lazy_alphas(const LazyArgs &a, int w0, int nj, float (&alpha)[kLzWin]) {
@@ -1294,7 +1395,7 @@ __device__ __forceinline__ void lazy_catchup_row(const LazyArgs &a, int step, in
   lazy_alphas(a, w0, step - w0, alpha);
 #pragma unroll
   for (int j = 0; j < kLzWin; ++j) sq[j] = 0.f;
-  lazy_replay(x, ta - w0, step - w0, alpha, a.two_l2, sq);
+  lazy_replay(x, ta - w0, step - w0, alpha, a.two_l2, sq, a.W, a.M, a.V, e);
   reinterpret_cast<float4 *>(a.W)[e] = x.w;
   reinterpret_cast<float4 *>(a.M)[e] = x.m;
   reinterpret_cast<float4 *>(a.V)[e] = x.v;
@@ -1420,7 +1521,7 @@ __global__ __launch_bounds__(256) void k_lazy_flush(LazyArgs a) {
 #pragma unroll
     for (int j = 0; j < kLzWin; ++j) sq[j] = 0.f;
     if (jt < nj) {
-      lazy_replay(x, jt, nj, alpha, a.two_l2, sq);
+      lazy_replay(x, jt, nj, alpha, a.two_l2, sq, a.W, a.M, a.V, e);
       if (kNT) {
         st_nt(reinterpret_cast<float4 *>(a.W) + e, x.w);
         st_nt(reinterpret_cast<float4 *>(a.M) + e, x.m);
@@ -1469,6 +1570,10 @@ __global__ __launch_bounds__(256) void k_lazy_flush(LazyArgs a) {
   tick(a.ticks, 1);
 }
 
+// (Measured and not built: the window's flush on a side stream beside the NEXT window's steps — emulated with a
+// flush that replays every row regardless of state, 1 / 2 / 4 / 8 / 32 workgroups per CU, timing only: 0.095 / 0.100 /
+// 0.100 / 0.102 / 0.103 ms per step against 0.101 — the latency-bound step kernels lose beside the VALU-bound flush
+// what the flush gains beside them.)
 // one workgroup of 16 waves: wave (2 j + table) sums the flush's block partials of step j in a fixed order, then
 // one thread completes the History sums of the window's steps in step order and opens the next window
 __global__ __launch_bounds__(1024) void k_lazy_reduce(LazyArgs a) {
