@@ -190,6 +190,10 @@ class DistTrainEngine:
                 with torch.cuda.device(self.device):
                     rc = lib.anirec_dist_comm_create(raw, self.rank, self.world, C.byref(h))
         finally:
+            try:
+                C.CDLL(None).fflush(None)     # RCCL printf()s into libc's buffer: drain it while fd 1 is still stderr
+            except OSError:
+                pass
             os.dup2(saved, 1)
             os.close(saved)
         _lib.check(rc, "anirec_rccl_unique_id / anirec_dist_comm_create")
