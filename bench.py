@@ -195,10 +195,24 @@ def run_single(workload, steps, warmup, batch, use_graph=True, cpu_baseline=True
                                                   source="anirec_train.hip") if tag else None,
                            "algorithmic_bytes_per_launch": alg, "avg_launch_ms": fl_ms, "steps_per_launch": win,
                            "moved_bytes_per_launch": moved, "moved_gbs": moved / (fl_ms * 1e-3) / 1e9,
-                           "moved_frac": moved / (fl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        per_step = (lazy_ms["lazy_catchup"] + lazy_ms["fwd"] + lazy_ms["head"] + lazy_ms["bwd"] + lazy_ms["lazy_adam"]
+                           "moved_frac": moved / (fl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "note": "frac > 1 is not a measurement error: `achieved` is on the bytes the DENSE algorithm of "
+                                   "SURVEY 8(d) would move for the %d steps one launch covers (28 B/element/step); the lazy "
+                                   "update applies those steps to every row in one pass, so it really moves 24 B/element per "
+                                   "launch (`moved_*`, `traffic`) and is bound by its IEEE sqrt + divide arithmetic.  Tables, "
+                                   "Adam moments and scalar state are bit-identical to the dense path "
+                                   "(dense_kernel_roofline) after every run() call, timed region included." % round(win)}
+        per_step = (lazy_ms["fwd"] + lazy_ms["head"] + lazy_ms["bwd"] + lazy_ms["lazy_adam"]
                     + (fl_ms + lazy_ms["lazy_reduce"]) / win)
         out["step_roofline"]["sum_of_kernels_ms"] = per_step
+        # what the lazy step really moves: the gathers, ~15 000 touched rows x (W, M, V) read + written twice (catch-up,
+        # sparse step), and 1/8 of the flush's pass
+        touched = 2 * 15_000 * 128 * 4 * 3 * 2
+        moved_step = (FWD_BYTES_PER_RATING + BWD_BYTES_PER_RATING) * batch + touched + moved / win
+        out["step_roofline"]["moved_bytes_per_step_estimate"] = moved_step
+        out["step_roofline"]["moved_frac"] = moved_step / (dt / steps) / 1e9 / HBM_PEAK_GBS
+        out["step_roofline"]["note"] = ("frac is on the dense algorithm's bytes (SURVEY 8(d)): above 1 because the lazy update "
+                                        "moves about a fifth of them (moved_frac)")
         out["dense_kernel_roofline"] = dense_roof
     else:
         out["roofline"] = dense_roof
