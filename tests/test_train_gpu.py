@@ -336,3 +336,32 @@ def test_lazy_adam_is_bitwise_the_dense_update(use_graph):
     rd, rz = d.read_state(), z.read_state()
     assert torch.equal(d.W, z.W) and abs(float(rd["last_loss"]) - float(rz["last_loss"])) <= 3e-6 * abs(float(rd["last_loss"]))
     d.close(); z.close()
+
+
+def test_fit_with_the_lazy_update_returns_the_dense_history_and_tables():
+    """`trainer.fit` end to end (epoch shuffles, ragged last batch, graph blocks + eager tail, validation between the
+    epochs, best-weights snapshot) over an engine with the lazy dense Adam and one with the dense kernel: the tables,
+    the head and every optimizer slot `model.save` would hold are bit-identical; the History columns agree to the
+    rounding of the L2 sum inside the loss (mse, val_mse and lr are equal)."""
+    from anime_recommendations_amd import data, trainer
+    from anime_recommendations_amd.engine import TrainEngine
+    df = data.synth_user_stats(n_users=6000, n_anime=700, n_ratings=40_000, seed=11)
+    table = data.encode_frame(df)
+    cfg = trainer.FitConfig(epochs=4, batch_size=700, test_size=1500, verbose=0, seed=3, arena_steps=16)
+    res = {}
+    for lazy in (False, True):
+        eng = TrainEngine(table.n_users, table.n_anime, max_batch=cfg.batch_size, l2=cfg.l2_reg_factor,
+                          arena_steps=cfg.arena_steps, lazy=lazy)
+        assert eng.lazy == lazy
+        res[lazy] = trainer.fit(table, cfg, engine=eng)
+        eng.close()
+    d, z = res[False], res[True]
+    assert np.array_equal(d.U, z.U) and np.array_equal(d.A, z.A) and d.head == z.head
+    assert np.array_equal(d.best_U, z.best_U) and np.array_equal(d.best_A, z.best_A) and d.best_epoch == z.best_epoch
+    assert sorted(d.optimizer) == sorted(z.optimizer)
+    for k in d.optimizer:
+        assert np.array_equal(np.asarray(d.optimizer[k]), np.asarray(z.optimizer[k])), k
+    for k in ("mse", "val_mse", "lr"):
+        assert d.history[k] == z.history[k], k
+    for k in ("loss", "val_loss"):
+        np.testing.assert_allclose(d.history[k], z.history[k], rtol=3e-6, atol=0)
