@@ -79,6 +79,11 @@ static_assert(kMaxSplit == 4, "cnt2 rows are read as one int4");
 // <= 2 * 128 * 2^-24 = 1.6e-5; the threshold bias folded into the accumulator adds <= 5e-7.
 // 0.000977 + 0.000017 < 0.00101.
 constexpr float kEpsMfma = 0.00101f;
+// The k-th largest score of a row is found by a bitwise radix select over order-preserving keys.  Every use of it is a
+// LOWER bound (a threshold below it, a survivor window below it), so the select stops kSelLow bits early: the prefix
+// with its low bits cleared is <= the true k-th key, off by < 2^(kSelLow-23) relative (1.2e-4 at 0.3, an eighth of eps),
+// for 20 ballot steps per row instead of 32.
+constexpr int kSelLow = 12;
 constexpr float kThetaInit = -4.0f;  // below every cosine; finite so that (score - theta) stays finite
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -194,7 +199,7 @@ __device__ __forceinline__ void refresh_row(const CandArgs &a, uint2 *cand_row, 
     u[j] = e < c ? f2key(__uint_as_float(en[j].x)) : 0u;
   }
   uint32_t prefix = 0;
-  for (int bit = 31; bit >= 0; --bit) {
+  for (int bit = 31; bit >= kSelLow; --bit) {
     const uint32_t trial = prefix | (1u << bit);
     int cge = 0;  // wave-uniform: ballots + scalar popcounts, no cross-lane shuffles
 #pragma unroll
@@ -219,39 +224,42 @@ __device__ __forceinline__ void refresh_row(const CandArgs &a, uint2 *cand_row, 
   }
 }
 
+// Fold what a split super-step left in the regions behind the kept entries of a row (all regions are read before the
+// first write: the destination may run into them); returns the new entry count.  The entries a lane writes here are
+// read back by other lanes of the SAME wave afterwards (the caller's loads follow in program order).
+__device__ __forceinline__ int fold_regions(uint2 *cand_row, int32_t *cnt_row, int32_t *cnt2_row, int c, int lane) {
+  const int4 c2 = *reinterpret_cast<const int4 *>(cnt2_row);
+  if (!(c2.x | c2.y | c2.z | c2.w)) return c;
+  const int cs[kMaxSplit] = {c2.x, c2.y, c2.z, c2.w};
+  constexpr int kRs = (kReg + 63) / 64;  // register slots per region
+  uint2 r[kMaxSplit][kRs];
+#pragma unroll
+  for (int sp = 0; sp < kMaxSplit; ++sp)
+#pragma unroll
+    for (int j = 0; j < kRs; ++j) {
+      const int e = lane + 64 * j;
+      r[sp][j] = e < cs[sp] ? cand_row[kKept + sp * kReg + e] : make_uint2(0u, 0u);
+    }
+#pragma unroll
+  for (int sp = 0; sp < kMaxSplit; ++sp) {
+#pragma unroll
+    for (int j = 0; j < kRs; ++j) {
+      const int e = lane + 64 * j;
+      if (e < cs[sp] && c + e < kCap) cand_row[c + e] = r[sp][j];
+    }
+    c += cs[sp];
+  }
+  c = min(c, kCap);
+  if (lane == 0) {
+    *reinterpret_cast<int4 *>(cnt2_row) = make_int4(0, 0, 0, 0);
+    *cnt_row = c;
+  }
+  return c;
+}
+
 __device__ __forceinline__ void refresh_one(const CandArgs &a, int row, int lane) {
   uint2 *cand_row = a.cand + (size_t)row * kCap;
-  int c = min(a.cnt[row], kCap);
-  {  // fold what a split super-step left in the regions behind the kept entries (all regions are read before
-     // the first write: the destination may run into them)
-    const int4 c2 = *reinterpret_cast<const int4 *>(a.cnt2 + (size_t)row * kMaxSplit);
-    if (c2.x | c2.y | c2.z | c2.w) {
-      const int cs[kMaxSplit] = {c2.x, c2.y, c2.z, c2.w};
-      constexpr int kRs = (kReg + 63) / 64;  // register slots per region
-      uint2 r[kMaxSplit][kRs];
-#pragma unroll
-      for (int sp = 0; sp < kMaxSplit; ++sp)
-#pragma unroll
-        for (int j = 0; j < kRs; ++j) {
-          const int e = lane + 64 * j;
-          r[sp][j] = e < cs[sp] ? cand_row[kKept + sp * kReg + e] : make_uint2(0u, 0u);
-        }
-#pragma unroll
-      for (int sp = 0; sp < kMaxSplit; ++sp) {
-#pragma unroll
-        for (int j = 0; j < kRs; ++j) {
-          const int e = lane + 64 * j;
-          if (e < cs[sp] && c + e < kCap) cand_row[c + e] = r[sp][j];
-        }
-        c += cs[sp];
-      }
-      c = min(c, kCap);
-      if (lane == 0) {
-        *reinterpret_cast<int4 *>(a.cnt2 + (size_t)row * kMaxSplit) = make_int4(0, 0, 0, 0);
-        a.cnt[row] = c;
-      }
-    }
-  }
+  const int c = fold_regions(cand_row, a.cnt + row, a.cnt2 + (size_t)row * kMaxSplit, min(a.cnt[row], kCap), lane);
   if (c < a.k_eff) return;  // not enough candidates yet (tiny tables): keep the threshold
   if (c <= 64)
     refresh_row<1>(a, cand_row, row, c, lane);
@@ -640,8 +648,9 @@ struct RerankArgs {
   const int32_t *qidx;     // [nq] index of the query row in the key table (self exclusion) or -1
   int nq, n, k, k_eff;     // k_eff = k + 1 when the query itself must be dropped
   int exclude_self;
-  const uint2 *cand;
-  const int32_t *cnt;
+  uint2 *cand;
+  int32_t *cnt;
+  int32_t *cnt2;           // split regions the last super-step left (folded here: no k_refresh after the last step)
   const float *theta;
   int32_t *flags;          // bit1: incomplete window / too many survivors / too few candidates
   int32_t *out_idx;        // [nq][k]
@@ -668,10 +677,11 @@ constexpr int kMaxSurv = 256;
 // was 1.6-2.5x SLOWER at k = 10 (a dozen survivors: the sort's 21 dependent cross-lane stages and the tile's LDS
 // footprint cost more than the old rank loop); removing its fetch, its chain or its sort one at a time changed nothing
 // (533-548 us).  Dropped: the bytes are the floor.
-template <bool kPredict>
-__device__ __forceinline__ void rerank_one(const RerankArgs &a, int row, int lane, float *qs, int32_t *sidx, float *sval) {
+// kSlots = ceil(entries / 64) register slots per lane, as in refresh_row: after the last refresh a row holds about
+// 2 k entries, so the 32-step select and the survivor scan run over 2-4 slots, not kCap / 64.
+template <bool kPredict, int kSlots>
+__device__ __forceinline__ void rerank_row(const RerankArgs &a, int row, int c, int lane, float *qs, int32_t *sidx, float *sval) {
   const size_t base = (size_t)row * kCap;
-  const int c = a.cnt[row];
   const int qrow = kPredict ? -1 : a.qidx[row];
   const int self = (!kPredict && a.exclude_self) ? qrow : -1;
   // query row (fp32) into LDS
@@ -680,11 +690,11 @@ __device__ __forceinline__ void rerank_one(const RerankArgs &a, int row, int lan
     qs[lane] = q[lane];
     qs[lane + 64] = q[lane + 64];
   }
-  float sc[kCap / 64];
-  int32_t id[kCap / 64];
-  uint32_t u[kCap / 64];
+  float sc[kSlots];
+  int32_t id[kSlots];
+  uint32_t u[kSlots];
 #pragma unroll
-  for (int j = 0; j < kCap / 64; ++j) {
+  for (int j = 0; j < kSlots; ++j) {
     const int e = lane + 64 * j;
     const uint2 en = e < c ? a.cand[base + e] : make_uint2(0u, 0u);
     sc[j] = __uint_as_float(en.x);
@@ -699,11 +709,11 @@ __device__ __forceinline__ void rerank_one(const RerankArgs &a, int row, int lan
   if (c < kk) bad = true;
   // tau = kk-th largest bf16 score
   uint32_t prefix = 0;
-  for (int bit = 31; bit >= 0; --bit) {
+  for (int bit = 31; bit >= kSelLow; --bit) {
     const uint32_t trial = prefix | (1u << bit);
     int cge = 0;
 #pragma unroll
-    for (int j = 0; j < kCap / 64; ++j) cge += __popcll(__ballot(u[j] >= trial));
+    for (int j = 0; j < kSlots; ++j) cge += __popcll(__ballot(u[j] >= trial));
     if (cge >= kk) prefix = trial;
   }
   const float tau = key2f(prefix);
@@ -713,7 +723,7 @@ __device__ __forceinline__ void rerank_one(const RerankArgs &a, int row, int lan
   int ns = 0;
   const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
-  for (int j = 0; j < kCap / 64; ++j) {
+  for (int j = 0; j < kSlots; ++j) {
     const bool kp = u[j] != 0u && sc[j] >= lo;
     const unsigned long long m = __ballot(kp);
     if (kp) {
@@ -792,6 +802,18 @@ __device__ __forceinline__ void rerank_one(const RerankArgs &a, int row, int lan
     a.out_idx[(size_t)row * a.k + i] = -1;
     a.out_score[(size_t)row * a.k + i] = __uint_as_float(0x7FC00000u);
   }
+}
+
+template <bool kPredict>
+__device__ __forceinline__ void rerank_one(const RerankArgs &a, int row, int lane, float *qs, int32_t *sidx, float *sval) {
+  const int c = fold_regions(a.cand + (size_t)row * kCap, a.cnt + row, a.cnt2 + (size_t)row * kMaxSplit,
+                             min(a.cnt[row], kCap), lane);
+  if (c <= 128)
+    rerank_row<kPredict, 2>(a, row, c, lane, qs, sidx, sval);
+  else if (c <= 256)
+    rerank_row<kPredict, 4>(a, row, c, lane, qs, sidx, sval);
+  else
+    rerank_row<kPredict, kCap / 64>(a, row, c, lane, qs, sidx, sval);
 }
 
 template <bool kPredict>
@@ -922,7 +944,6 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
   }
   if (max_split > kMaxSplit) max_split = kMaxSplit;
   if (max_split < 1 || ca.k_eff + 16 > kKept) max_split = 1;  // the kept entries (k_eff + the 2 eps window) must fit
-  bool regions_used = false;
   for (int t0 = 0, step = first; t0 < ntiles;) {
     const int t1 = t0 + step < ntiles ? t0 + step : ntiles;
     ca.tile0 = t0;
@@ -932,7 +953,6 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
     if (splits > 1 && splits < min_split) splits = 1;
     ca.splits = splits;
     const dim3 grid2(grid.x, splits);
-    regions_used = splits > 1;
 #define ANIREC_LAUNCH_CAND(D, M)                                                                    \
   do {                                                                                              \
     const size_t shm = (M) ? (size_t)(wide ? 8 : 4) * 3 * 512 : 0;  /* the waves' LDS mask images */   \
@@ -963,8 +983,8 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
       timed.push_back(ev0);
       timed.push_back(ev1);
     }
-    // (after the last super-step only to fold the split regions: the re-rank reads one list per row)
-    if (t1 < ntiles || regions_used) hipLaunchKernelGGL(k_refresh, dim3(side_grid(nq)), dim3(64), 0, s, ca);
+    // (none after the last super-step: the re-rank folds the split regions itself)
+    if (t1 < ntiles) hipLaunchKernelGGL(k_refresh, dim3(side_grid(nq)), dim3(64), 0, s, ca);
     ANIREC_HIP_CHECK(hipGetLastError());
     if (mid_ev && (long long)t1 * 100 >= (long long)ntiles * mid_pct) {
       ANIREC_HIP_CHECK(hipEventRecord(mid_ev, s));
@@ -1136,6 +1156,7 @@ static int run_batch(const float *What, const _Float16 *Wb, int n, const int32_t
   ra.exclude_self = exclude_self ? 1 : 0;
   ra.cand = lb.cand;
   ra.cnt = lb.cnt;
+  ra.cnt2 = ca.cnt2;
   ra.theta = lb.theta;
   ra.flags = flags;
   ra.out_idx = out_idx;
@@ -1477,6 +1498,7 @@ int anirec_predict_topk_mfma(const float *U, const float *A, int32_t n_anime, co
   ra.exclude_self = 0;
   ra.cand = cand;
   ra.cnt = cnt;
+  ra.cnt2 = ca.cnt2;
   ra.theta = theta;
   ra.flags = flags_out;
   ra.out_idx = out_idx;
