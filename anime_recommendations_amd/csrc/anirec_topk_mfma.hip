@@ -82,7 +82,9 @@ constexpr float kEpsMfma = 0.00101f;
 // The k-th largest score of a row is found by a bitwise radix select over order-preserving keys.  Every use of it is a
 // LOWER bound (a threshold below it, a survivor window below it), so the select stops kSelLow bits early: the prefix
 // with its low bits cleared is <= the true k-th key, off by < 2^(kSelLow-23) relative (1.2e-4 at 0.3, an eighth of eps),
-// for 20 ballot steps per row instead of 32.
+// for 20 ballot steps per row instead of 32.  (Walking the row's proven threshold bits for free — no ballot at its
+// 1-bits while the prefix still equals it — was measured too: the data-dependent branch in the loop cost more than the
+// 7-9 ballots it saved, 0.64 vs 0.62 ms on the 18 k job.)
 constexpr int kSelLow = 12;
 constexpr float kThetaInit = -4.0f;  // below every cosine; finite so that (score - theta) stays finite
 
@@ -680,7 +682,8 @@ constexpr int kMaxSurv = 256;
 // kSlots = ceil(entries / 64) register slots per lane, as in refresh_row: after the last refresh a row holds about
 // 2 k entries, so the 32-step select and the survivor scan run over 2-4 slots, not kCap / 64.
 template <bool kPredict, int kSlots>
-__device__ __forceinline__ void rerank_row(const RerankArgs &a, int row, int c, int lane, float *qs, int32_t *sidx, float *sval) {
+__device__ __forceinline__ void rerank_row(const RerankArgs &a, int row, int c, int lane, float *qs, int32_t *sidx, float *sval,
+                                           unsigned long long *skey) {
   const size_t base = (size_t)row * kCap;
   const int qrow = kPredict ? -1 : a.qidx[row];
   const int self = (!kPredict && a.exclude_self) ? qrow : -1;
@@ -775,21 +778,49 @@ __device__ __forceinline__ void rerank_row(const RerankArgs &a, int row, int c, 
       return;
     }
   }
-  // rank by (score desc, index asc); the query itself is dropped
+  // rank by (score desc, index asc); the query itself is dropped.  One 64-bit key per survivor — the exact path's
+  // order-preserving score key (NaN after every number) above the inverted index — turns the O(survivors^2) rank into
+  // one LDS broadcast read, one compare and one add per pair: this loop was 7x the instructions of the score chain.
   for (int i = lane; i < ns; i += 64) {
+    const float sv = sval[i];
+    uint32_t hi = __float_as_uint(sv);
+    hi = (hi & 0x80000000u) ? ~hi : (hi | 0x80000000u);
+    hi = sv != sv ? 1u : (hi < 2u ? 2u : hi);
     const int mi = sidx[i];
-    if (mi == self) continue;
-    const float ms = sval[i];
-    int rank = 0;
-    for (int j = 0; j < ns; ++j) {
-      const int oj = sidx[j];
-      if (oj == self) continue;
-      const float os = sval[j];
-      rank += (os > ms || (os == ms && oj < mi)) ? 1 : 0;
+    skey[i] = mi == self ? 0ull : ((unsigned long long)hi << 32) | (uint32_t)~mi;
+  }
+  __builtin_amdgcn_wave_barrier();
+  {
+    constexpr int kOwn = kMaxSurv / 64;
+    unsigned long long mk[kOwn];
+    int rank[kOwn];
+#pragma unroll
+    for (int t = 0; t < kOwn; ++t) {
+      const int i = lane + 64 * t;
+      mk[t] = i < ns ? skey[i] : ~0ull;
+      rank[t] = 0;
     }
-    if (rank < a.k) {
-      a.out_idx[(size_t)row * a.k + rank] = mi;
-      a.out_score[(size_t)row * a.k + rank] = ms;
+    const int own = (ns + 63) >> 6;  // wave-uniform
+    if (own <= 2) {
+      for (int j = 0; j < ns; ++j) {
+        const unsigned long long kj = skey[j];
+        rank[0] += kj > mk[0] ? 1 : 0;
+        rank[1] += kj > mk[1] ? 1 : 0;
+      }
+    } else {
+      for (int j = 0; j < ns; ++j) {
+        const unsigned long long kj = skey[j];
+#pragma unroll
+        for (int t = 0; t < kOwn; ++t) rank[t] += kj > mk[t] ? 1 : 0;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kOwn; ++t) {
+      const int i = lane + 64 * t;
+      if (i < ns && mk[t] != 0ull && rank[t] < a.k) {
+        a.out_idx[(size_t)row * a.k + rank[t]] = sidx[i];
+        a.out_score[(size_t)row * a.k + rank[t]] = sval[i];
+      }
     }
   }
   // fewer than k real neighbours (tiny tables): pad
@@ -805,15 +836,16 @@ __device__ __forceinline__ void rerank_row(const RerankArgs &a, int row, int c, 
 }
 
 template <bool kPredict>
-__device__ __forceinline__ void rerank_one(const RerankArgs &a, int row, int lane, float *qs, int32_t *sidx, float *sval) {
+__device__ __forceinline__ void rerank_one(const RerankArgs &a, int row, int lane, float *qs, int32_t *sidx, float *sval,
+                                           unsigned long long *skey) {
   const int c = fold_regions(a.cand + (size_t)row * kCap, a.cnt + row, a.cnt2 + (size_t)row * kMaxSplit,
                              min(a.cnt[row], kCap), lane);
   if (c <= 128)
-    rerank_row<kPredict, 2>(a, row, c, lane, qs, sidx, sval);
+    rerank_row<kPredict, 2>(a, row, c, lane, qs, sidx, sval, skey);
   else if (c <= 256)
-    rerank_row<kPredict, 4>(a, row, c, lane, qs, sidx, sval);
+    rerank_row<kPredict, 4>(a, row, c, lane, qs, sidx, sval, skey);
   else
-    rerank_row<kPredict, kCap / 64>(a, row, c, lane, qs, sidx, sval);
+    rerank_row<kPredict, kCap / 64>(a, row, c, lane, qs, sidx, sval, skey);
 }
 
 template <bool kPredict>
@@ -821,8 +853,9 @@ __global__ __launch_bounds__(64) void k_rerank(RerankArgs a) {  // bounded grid,
   __shared__ float qs[kDim];
   __shared__ int32_t sidx[kMaxSurv];
   __shared__ float sval[kMaxSurv];
+  __shared__ unsigned long long skey[kMaxSurv];
   for (int row = blockIdx.x; row < a.nq; row += gridDim.x) {
-    rerank_one<kPredict>(a, row, threadIdx.x, qs, sidx, sval);
+    rerank_one<kPredict>(a, row, threadIdx.x, qs, sidx, sval, skey);
     __syncthreads();  // the next row rewrites qs / sidx / sval
   }
 }
