@@ -1,10 +1,12 @@
 set -e
 cd $GRAFT_REPO_ROOT
-timeout -k 10 500 python -m pytest tests/test_infer_gpu.py tests/test_recs_gpu.py -x -q -m gpu 2>&1 | tail -3
-for i in 1 2; do
-for L in scripts/_v/libanirec_head.so anime_recommendations_amd/libanirec.so; do
-ANIREC_LIB_PATH=$PWD/$L timeout -k 10 120 python scripts/time_topk_reps.py 18000 18000 100 5
-ANIREC_LIB_PATH=$PWD/$L timeout -k 10 120 python scripts/time_topk_reps.py 350000 350000 100 4
-ANIREC_LIB_PATH=$PWD/$L timeout -k 10 120 python scripts/time_topk_reps.py 350000 65536 10 3
-done; done
-timeout -k 10 300 python scripts/time_predict_topk.py 2>&1 | tail -1
+export TMPDIR=/tmp
+for ph in 0 1 2 3 9; do
+export ANIREC_RR_PHASE=$ph
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/rr$ph -- python3 scripts/time_topk.py 18000 18000 100 > gpurun_out/rr$ph.log 2>&1 || true
+f=$(find gpurun_out/rr$ph -name '*kernel_stats.csv' | head -1)
+echo "phase $ph 18k: $(grep rerank $f | cut -d, -f1-4 | tail -1)"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/rs$ph -- python3 scripts/time_topk.py 350000 65536 100 > gpurun_out/rs$ph.log 2>&1 || true
+f=$(find gpurun_out/rs$ph -name '*kernel_stats.csv' | head -1)
+echo "phase $ph 350k/65536: $(grep rerank $f | cut -d, -f1-4 | tail -1)"
+done
