@@ -683,7 +683,7 @@ constexpr int kMaxSurv = 256;
 // empty kernel 5 / 9 us, + region fold 12 / 21 us, + buffer load, select and survivor scan 25 / 49 us, + the exact
 // score chain 132 / 282 us, + rank and output 137 / 290 us.  The chain phase is the row gather: 110 rows x 512 B per
 // query = 1.0 GB from the Infinity Cache in 107 us at 18 k (9.5 TB/s; the 9.2 MB table does not fit one XCD's 4 MB L2)
-// and 3.7 GB from HBM in 2 x 233 us at 350 k (7.9 TB/s).  Fetching the same rows as 128-B slices through an LDS tile
+// and 3.7 GB from HBM and Infinity Cache hits in 2 x 233 us at 350 k (7.9 TB/s).  Fetching the same rows as 128-B slices through an LDS tile
 // (4 line requests per row instead of 32) changed neither case (0.599 vs 0.598 ms for the 18 k job).
 // kSlots = ceil(entries / 64) register slots per lane, as in refresh_row: after the last refresh a row holds about
 // 2 k entries, so the 32-step select and the survivor scan run over 2-4 slots, not kCap / 64.
