@@ -120,6 +120,9 @@ PROTOTYPES = {
     "anirec_cosine_topk_job_plan": (C.c_int, [_i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                               C.POINTER(C.c_int32)]),
     "anirec_cosine_topk_job_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "anirec_cosine_topk_allpairs_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "anirec_cosine_topk_allpairs_plan": (C.c_int, [_i32, _i32, _i32, _i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                                   C.POINTER(C.c_int32)]),
     "anirec_cosine_topk_job": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, C.c_float, C.POINTER(C.c_int32), _i32,
                                          _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "anirec_topk_mfma_timing": (C.c_int, [_i32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),

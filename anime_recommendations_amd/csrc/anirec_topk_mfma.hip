@@ -179,7 +179,21 @@ struct CandArgs {
   unsigned long long *dbg;  // kDbg == 2: [0] total appends
   const uint32_t *watched;  // kMask: [nq][wwords] per-query key mask, bit set = key excluded (model_recs)
   int wwords;
+  // all-pairs job (every key row is a query row): the key stream of a query batch skips the tiles of EARLIER batches
+  // — logical tile t is physical tile t (t < map_lo) or t + map_skip — because those batches computed the same dot
+  // products and passed every score >= the job's prior on to this batch's rows.  kSym launches (the tiles of LATER
+  // batches) do that for the batches to come: a score passes if it reaches the PRIOR theta0 (every later row starts
+  // from it): it is written to the wave's own log {score, query row, key row} (ballot-ranked like the row's own
+  // appends: no atomic, nothing to wait for inside the MFMA loop), and to the query row's buffer if it also reaches
+  // that row's threshold.  k_scatter_log deals the logs to the key rows' inboxes behind the launch.
+  int map_lo, map_skip;
+  int row0;                 // key-table row of this batch's first query
+  const float *theta0_dev;  // the prior (device word)
+  uint4 *log;               // [waves of the launch][lcap]
+  int32_t *logcnt;          // [waves of the launch] entries a wave wanted to write (may exceed lcap: overflow)
+  int lcap;
 };
+constexpr int kInbox = 256;
 
 // ------------------------------------------------------------------------------------
 // k_refresh: one wave per query row, between two super-steps of the key stream.
@@ -259,6 +273,66 @@ __device__ __forceinline__ int fold_regions(uint2 *cand_row, int32_t *cnt_row, i
   return c;
 }
 
+// all-pairs job: what earlier batches dropped into the inbox of key-table row g goes behind the row's entries.
+// More than the inbox or the buffer holds: `ovf` (the caller flags the row; it is re-run without the shortcut).
+__device__ __forceinline__ int fold_inbox(uint2 *cand_row, int32_t *cnt_row, const uint2 *inbox_row, const int32_t *icnt_row,
+                                          float theta_row, int c, int lane, bool &ovf) {
+  int ci = *icnt_row;
+  if (ci <= 0) return c;
+  if (ci > kInbox) {
+    ovf = true;
+    ci = kInbox;
+  }
+  // only what the row's threshold still lets through (the inbox was filled against the prior)
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int e0 = 0; e0 < ci; e0 += 64) {
+    const int e = e0 + lane;
+    const uint2 en = e < ci ? inbox_row[e] : make_uint2(0u, 0u);
+    const bool kp = e < ci && __uint_as_float(en.x) >= theta_row;
+    const unsigned long long m = __ballot(kp);
+    const int pos = c + __popcll(m & lt);
+    if (kp && pos < kCap) cand_row[pos] = en;
+    c += __popcll(m);
+  }
+  if (c > kCap) {
+    ovf = true;
+    c = kCap;
+  }
+  if (lane == 0) *cnt_row = c;
+  return c;
+}
+
+// start of a batch of the all-pairs job: the inbox of the parity whose writers are done (the batches before this one
+// on the same chain) becomes the rows' first candidates; the k_refresh that follows turns them into thresholds
+__global__ __launch_bounds__(64) void k_merge_inbox(uint2 *cand, int32_t *cnt, int32_t *flags, int nq, int row0,
+                                                    const uint2 *inbox, const int32_t *icnt) {
+  const int row = blockIdx.x;
+  if (row >= nq) return;
+  bool ovf = false;
+  const size_t g = (size_t)row0 + row;
+  (void)fold_inbox(cand + (size_t)row * kCap, cnt + row, inbox + g * kInbox, icnt + g, -INFINITY, 0, threadIdx.x, ovf);
+  if (ovf && threadIdx.x == 0) flags[row] |= 1;
+}
+
+// behind a kSym launch: the waves' logs go to the key rows' inboxes (slot = atomic counter of the row; the order of
+// the entries in an inbox is arbitrary, the re-rank's result does not depend on it).  A log that overflowed lost
+// pairs nobody can name: *ovf marks the job, every all-pairs batch then comes out flagged (re-run by the caller).
+constexpr int kLogCap = 8192;  // entries per wave and launch; the host bounds the launches' lengths to fit
+__global__ __launch_bounds__(256) void k_scatter_log(const uint4 *log, const int32_t *logcnt, int lcap, uint2 *inbox,
+                                                     int32_t *icnt, int32_t *ovf) {
+  const size_t wv = blockIdx.x;
+  int c = logcnt[wv];
+  if (c > lcap) {
+    if (threadIdx.x == 0) *ovf = 1;
+    c = lcap;
+  }
+  for (int e = threadIdx.x; e < c; e += 256) {
+    const uint4 en = log[wv * (size_t)lcap + e];
+    const int slot = atomicAdd(icnt + en.z, 1);
+    if (slot < kInbox) inbox[(size_t)en.z * kInbox + slot] = make_uint2(en.x, en.y);
+  }
+}
+
 __device__ __forceinline__ void refresh_one(const CandArgs &a, int row, int lane) {
   uint2 *cand_row = a.cand + (size_t)row * kCap;
   const int c = fold_regions(cand_row, a.cnt + row, a.cnt2 + (size_t)row * kMaxSplit, min(a.cnt[row], kCap), lane);
@@ -292,9 +366,10 @@ __global__ __launch_bounds__(64) void k_refresh(CandArgs a) {
 // MFMA and is used when the queries fill the chip that way; kWaves = 4 (two workgroups per CU) otherwise.
 // kMask: a candidate is dropped at append time when its bit in the query's own mask row is set (the
 // "already watched" set of model_recs); the mask words reach a wave-private LDS image by LDS-DMA two tiles ahead.
-template <int kDbg, int kWaves, bool kMask = false>  // kDbg 0: product; 1: no filter (timing only); 2: count appends; 4: stamps
+template <int kDbg, int kWaves, bool kMask = false, bool kSym = false>  // kDbg 0: product; 1: no filter (timing only); 2: count appends; 4: stamps
 // (host-side mode 16: after the product run, one launch over all keys with the final / with unreachable thresholds)
 __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
+  static_assert(!(kSym && (kMask || kDbg != 0)), "the all-pairs variant exists for the product build only");
   constexpr int kBM = 32 * kWaves;
   constexpr int kDma = 32 / kWaves;  // LDS-DMA instructions per wave per key tile (4 key rows each)
   __shared__ __attribute__((aligned(16))) uint4 Ks[2][kBN * 16];  // 2 x 32 KB
@@ -333,7 +408,8 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
   const uint32_t ks_base =
       (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&Ks[0][0] + (uint32_t)wu * (1024u * kDma);
   auto dma_tile = [&](int t, int buf) {
-    const char *base = reinterpret_cast<const char *>(a.Wb) + (size_t)t * (kBN * 256);
+    const int pt = t < a.map_lo ? t : t + a.map_skip;
+    const char *base = reinterpret_cast<const char *>(a.Wb) + (size_t)pt * (kBN * 256);
     const uint32_t l0 = ks_base + (uint32_t)buf * (kBN * 256);
 #pragma unroll
     for (int i = 0; i < kDma; ++i)
@@ -392,6 +468,9 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
   // rows: the rows are private to the wave, so their thresholds and buffer counts live in registers
   // (replicated over the 16 lanes of a quarter-wave) — no LDS, no atomics in the loop.
   f32x4 nthr[2];  // -theta: loop-invariant C-in of the MFMA chains (no per-tile copies)
+  float rthr[2][4];  // kSym: C-in is -theta0 for every row; the row's own test is score - theta0 >= theta - theta0
+  uint32_t livem = 0;  // kSym: bit 4 rb + i = the row exists
+  const float th0 = kSym ? a.theta0_dev[0] : 0.f;
   int cntr[2][4];
   uint32_t rowoff[2][4];  // byte offset of the row's buffer (nq*kCap*8 < 2^32 is checked on the host)
 #pragma unroll
@@ -400,7 +479,14 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
     for (int i = 0; i < 4; ++i) {
       const int rl = q0 + 32 * w + 16 * rb + 4 * gq + i;
       const bool live = rl < a.nq;
-      nthr[rb][i] = live ? -a.theta[rl] : -INFINITY;
+      if (kSym) {
+        nthr[rb][i] = -th0;
+        rthr[rb][i] = live ? a.theta[rl] - th0 : INFINITY;
+        livem |= live ? 1u << (4 * rb + i) : 0u;
+      } else {
+        nthr[rb][i] = live ? -a.theta[rl] : -INFINITY;
+        rthr[rb][i] = 0.f;
+      }
       // a split appends to its own (empty) region; the kept entries must then end before the regions begin
       cntr[rb][i] = (live && a.splits == 1) ? a.cnt[rl] : 0;
       if (live && a.splits > 1 && split == 0 && c16 == 0 && a.cnt[rl] > kKept) a.flags[rl] |= 1;
@@ -415,6 +501,11 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
   const uint32_t cap = a.splits > 1 ? (uint32_t)kReg : (uint32_t)kCap;  // entries this workgroup may append per row
   const uint32_t lt16 = (1u << c16) - 1u;
   const int sh16 = 16 * gq;
+  // kSym: this wave's log
+  const size_t wave_id = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kWaves + wu;
+  uint4 *const wlog = kSym ? a.log + wave_id * (size_t)a.lcap : nullptr;
+  uint32_t lcnt = 0;
+  const unsigned long long lt64 = (1ull << lane) - 1ull;
   char *const cand_bytes = reinterpret_cast<char *>(a.cand);
   // Touch the per-row registers here so the loads above are waited for BEFORE the loop: otherwise the
   // compiler parks an s_waitcnt vmcnt(0) at their first use inside the append path, where it also
@@ -422,7 +513,7 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(cntr[rb][i]), "v"(nthr[rb][i]));
+    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(cntr[rb][i]), "v"(nthr[rb][i]), "v"(rthr[rb][i]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // both DMA tiles have landed
   __syncthreads();
 
@@ -479,7 +570,17 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
         const int key = key0 + 16 * nb + c16;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          bool hit = cv[i] >= 0.f;
+          bool hit = cv[i] >= (kSym ? rthr[rb][i] : 0.f);
+          if (kSym) {  // the key's row will want this pair (every hit of the row's own test is one of these)
+            const bool ch = cv[i] >= 0.f && ((livem >> (4 * rb + i)) & 1u);
+            const unsigned long long cm = __ballot(ch);
+            if (!cm) continue;  // wave-uniform
+            const uint32_t lpos = lcnt + (uint32_t)__popcll(cm & lt64);
+            if (ch && lpos < (uint32_t)a.lcap)
+              wlog[lpos] = make_uint4(__float_as_uint(cv[i] - nthr[rb][i]),
+                                      (uint32_t)(a.row0 + q0 + 32 * w + 16 * rb + 4 * gq + i), (uint32_t)key, 0u);
+            lcnt += (uint32_t)__popcll(cm);
+          }
           if (kMask) {  // the row's 32 mask bits of this key block: one word of the wave's LDS mask image
             const uint32_t wbits = mk_l[moff + 4 * (16 * rb + 4 * gq + i)];
             hit = hit && ((wbits >> (16 * nb + c16)) & 1u) == 0u;
@@ -512,7 +613,8 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
   if (kDbg == 4) dbg_t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < nt; ++it) {
     const int buf = it & 1;
-    const int key0 = (tile_lo + it) * kBN;
+    const int lt = tile_lo + it;
+    const int key0 = (lt < a.map_lo ? lt : lt + a.map_skip) * kBN;
     const int ms = (it % 3) * 128;                     // this tile's slot in the wave's LDS mask image
     stage_fn(acc0, acc1, key0, buf, 2, ms + 0);        // filter block 0 | MFMA block 1 | fetch block 2
     stage_fn(acc1, acc0, key0 + 32, buf, 3, ms + 1);   // filter block 1 | MFMA block 2 | fetch block 3
@@ -546,6 +648,7 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
     d[2] = dbg_barrier;
     d[3] = (unsigned long long)nt;
   }
+  if (kSym && lane == 0) a.logcnt[wave_id] = (int32_t)lcnt;
   if (kDbg != 1 && c16 == 0) {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -653,6 +756,9 @@ struct RerankArgs {
   uint2 *cand;
   int32_t *cnt;
   int32_t *cnt2;           // split regions the last super-step left (folded here: no k_refresh after the last step)
+  const uint2 *inbox;      // all-pairs job: the inbox (indexed by key-table row = qidx[row]) still to be merged, or null
+  const int32_t *icnt;
+  const int32_t *sym_ovf;  // all-pairs job: a log overflowed somewhere (pairs lost): every row is unproven
   const float *theta;
   int32_t *flags;          // bit1: incomplete window / too many survivors / too few candidates
   int32_t *out_idx;        // [nq][k]
@@ -688,7 +794,8 @@ constexpr int kMaxSurv = 256;
 // kSlots = ceil(entries / 64) register slots per lane, as in refresh_row: after the last refresh a row holds about
 // 2 k entries, so the 32-step select and the survivor scan run over 2-4 slots, not kCap / 64.
 template <bool kPredict, int kSlots>
-__device__ __forceinline__ void rerank_row(const RerankArgs &a, int row, int c, int lane, float *qs, int32_t *sidx, float *sval,
+__device__ __forceinline__ void rerank_row(const RerankArgs &a, int row, int c, bool ovf, int lane, float *qs, int32_t *sidx,
+                                           float *sval,
                                            unsigned long long *skey) {
   const size_t base = (size_t)row * kCap;
   const int qrow = kPredict ? -1 : a.qidx[row];
@@ -710,7 +817,7 @@ __device__ __forceinline__ void rerank_row(const RerankArgs &a, int row, int c, 
     id[j] = e < c ? (int32_t)en.y : -1;
     u[j] = e < c ? f2key(sc[j]) : 0u;
   }
-  bool bad = (a.flags[row] & 1) != 0;
+  bool bad = ovf || (a.flags[row] & 1) != 0;
   const bool unnorm = a.unnorm != nullptr && a.unnorm[0] != 0;
   if (unnorm) bad = true;
   if (__ballot(qs[lane] != qs[lane] || qs[lane + 64] != qs[lane + 64])) bad = true;  // NaN query row
@@ -844,14 +951,19 @@ __device__ __forceinline__ void rerank_row(const RerankArgs &a, int row, int c, 
 template <bool kPredict>
 __device__ __forceinline__ void rerank_one(const RerankArgs &a, int row, int lane, float *qs, int32_t *sidx, float *sval,
                                            unsigned long long *skey) {
-  const int c = fold_regions(a.cand + (size_t)row * kCap, a.cnt + row, a.cnt2 + (size_t)row * kMaxSplit,
-                             min(a.cnt[row], kCap), lane);
+  int c = fold_regions(a.cand + (size_t)row * kCap, a.cnt + row, a.cnt2 + (size_t)row * kMaxSplit,
+                       min(a.cnt[row], kCap), lane);
+  bool ovf = !kPredict && a.sym_ovf != nullptr && a.sym_ovf[0] != 0;
+  if (!kPredict && a.inbox != nullptr) {
+    const size_t g = (size_t)a.qidx[row];
+    c = fold_inbox(a.cand + (size_t)row * kCap, a.cnt + row, a.inbox + g * kInbox, a.icnt + g, a.theta[row], c, lane, ovf);
+  }
   if (c <= 128)
-    rerank_row<kPredict, 2>(a, row, c, lane, qs, sidx, sval, skey);
+    rerank_row<kPredict, 2>(a, row, c, ovf, lane, qs, sidx, sval, skey);
   else if (c <= 256)
-    rerank_row<kPredict, 4>(a, row, c, lane, qs, sidx, sval, skey);
+    rerank_row<kPredict, 4>(a, row, c, ovf, lane, qs, sidx, sval, skey);
   else
-    rerank_row<kPredict, kCap / 64>(a, row, c, lane, qs, sidx, sval, skey);
+    rerank_row<kPredict, kCap / 64>(a, row, c, ovf, lane, qs, sidx, sval, skey);
 }
 
 template <bool kPredict>
@@ -919,13 +1031,55 @@ static int side_grid(int nq) {
   return (int)(g < nq ? g : nq);
 }
 
+// one batch of the all-pairs job (see CandArgs): its key stream and its inboxes
+struct SymPlan {
+  int map_lo, map_skip;  // logical -> physical key tiles
+  int sym_from;          // logical tile where the keys of later batches begin (== the stream's end: none)
+  int row0;
+  const float *theta0_dev;
+  uint2 *inbox_w;        // written (through the logs) by this batch's kSym launches
+  int32_t *icnt_w;
+  uint4 *log;            // this chain's log buffer: log_waves x kLogCap entries
+  int32_t *logcnt;
+  int32_t *ovf;          // job-wide: a log overflowed
+  const uint2 *inbox_start;  // merged before the first super-step (writers: earlier batches of this chain)
+  const int32_t *icnt_start;
+  const uint2 *inbox_end;    // merged by the re-rank (writers: the other chain, the batch before this one last)
+  const int32_t *icnt_end;
+  hipEvent_t done_ev;    // recorded behind this batch's last k_cand
+  hipEvent_t wait_ev;    // the previous batch's done_ev (other chain), or null
+};
+
+static void cand_defaults(CandArgs &ca) {
+  ca.map_lo = 0x7fffffff;
+  ca.map_skip = 0;
+  ca.row0 = 0;
+  ca.theta0_dev = nullptr;
+  ca.log = nullptr;
+  ca.logcnt = nullptr;
+  ca.lcap = 0;
+}
+
 static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, void *dbg_words,
                            unsigned long long *stamps, size_t n_waves, hipStream_t s, hipEvent_t mid_ev = nullptr,
-                           int mid_pct = 0, bool has_prior = false) {
-  const int ntiles = (n + kBN - 1) / kBN;
+                           int mid_pct = 0, bool has_prior = false, const SymPlan *sp = nullptr) {
+  int ntiles = (n + kBN - 1) / kBN;
+  int sym_from = 0x7fffffff;
+  if (sp) {
+    ca.map_lo = sp->map_lo;
+    ca.map_skip = sp->map_skip;
+    ca.row0 = sp->row0;
+    ca.theta0_dev = sp->theta0_dev;
+    ca.log = sp->log;
+    ca.logcnt = sp->logcnt;
+    ca.lcap = kLogCap;
+    ntiles -= sp->map_skip;
+    sym_from = sp->sym_from;
+  }
   // 256-row workgroups once they give every CU one (8 waves per CU either way); 128-row otherwise
   const char *wv = getenv("ANIREC_TOPK_WAVES");
-  const bool wide = wv ? atoi(wv) == 8 : nq >= 49152;
+  // (an all-pairs batch of 24 k rows or more: its launches are cut in three key ranges anyway)
+  const bool wide = wv ? atoi(wv) == 8 : (nq >= 49152 || (sp != nullptr && nq >= 24576));
   const dim3 grid(wide ? (nq + 255) / 256 : (nq + 127) / 128);
   const dim3 block(wide ? 512 : 256);
   int n_launch = 0;
@@ -984,7 +1138,17 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
   if (max_split > kMaxSplit) max_split = kMaxSplit;
   if (max_split < 1 || ca.k_eff + 16 > kKept) max_split = 1;  // the kept entries (k_eff + the 2 eps window) must fit
   for (int t0 = 0, step = first; t0 < ntiles;) {
-    const int t1 = t0 + step < ntiles ? t0 + step : ntiles;
+    int t1 = t0 + step < ntiles ? t0 + step : ntiles;
+    if (t0 < sym_from && t1 > sym_from) t1 = sym_from;  // a launch is all-pairs (keys of later batches) or it is not
+    const bool sym = t0 >= sym_from;
+    if (sym) {
+      // a wave logs about 32 rows x 128 keys x P(score >= prior) pairs per tile, the prior passing ~2.5 k_eff of a
+      // row's n scores: the launch is cut so that four times that fits the wave's log
+      const double per_tile = 32.0 * kBN * 2.5 * ca.k_eff / (double)n;
+      int lim = (int)(kLogCap / 4 / (per_tile > 1e-9 ? per_tile : 1e-9)) * max_split;
+      if (lim < 2 * max_split) lim = 2 * max_split;
+      if (t1 - t0 > lim) t1 = t0 + lim;
+    }
     ca.tile0 = t0;
     ca.tile1 = t1;
     int splits = (t0 == 0 && !(has_prior && first_pct > 0)) ? 1 : max_split;
@@ -1006,7 +1170,16 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
       ANIREC_HIP_CHECK(hipEventCreate(&ev1));
       ANIREC_HIP_CHECK(hipEventRecord(ev0, s));
     }
-    if (masked)
+    if (sym) {
+      const size_t lw = (size_t)grid2.x * grid2.y * (wide ? 8 : 4);
+      (void)hipMemsetAsync(ca.logcnt, 0, lw * 4, s);  // (workgroups of an empty split write nothing)
+      if (wide)
+        hipLaunchKernelGGL((k_cand<0, 8, false, true>), grid2, block, 0, s, ca);
+      else
+        hipLaunchKernelGGL((k_cand<0, 4, false, true>), grid2, block, 0, s, ca);
+      hipLaunchKernelGGL(k_scatter_log, dim3((unsigned)lw), dim3(256), 0, s, ca.log, ca.logcnt, kLogCap, sp->inbox_w,
+                         sp->icnt_w, sp->ovf);
+    } else if (masked)
       ANIREC_LAUNCH_CAND(0, true);
     else if (mode == 1)
       ANIREC_LAUNCH_CAND(1, false);
@@ -1146,7 +1319,7 @@ static LaneBufs carve_lane(char *p, size_t rows) {
 static int run_batch(const float *What, const _Float16 *Wb, int n, const int32_t *queries, int nq, int exclude_self, int k,
                      float theta0, const float *theta0_dev, const LaneBufs &lb, int32_t *unnorm, bool zero_unnorm,
                      int32_t *out_idx, float *out_score, int32_t *flags, int mode, void *dbg_words, hipStream_t s,
-                     hipEvent_t mid_ev = nullptr, int mid_pct = 0) {
+                     hipEvent_t mid_ev = nullptr, int mid_pct = 0, const SymPlan *sp = nullptr) {
   if ((size_t)nq * kCap * 8 >= ((size_t)1 << 32)) return ANIREC_EINVAL;  // 32-bit candidate offsets: batch the queries
   int b2 = (nq + 7) / 8;
   if (b2 > 8192) b2 = 8192;
@@ -1155,6 +1328,7 @@ static int run_batch(const float *What, const _Float16 *Wb, int n, const int32_t
   hipLaunchKernelGGL(k_to_f16, dim3(b2), dim3(256), 0, s, What, queries, nq, nq, nullptr, 1, lb.Qb, unnorm);
   ANIREC_HIP_CHECK(hipGetLastError());
   CandArgs ca;
+  cand_defaults(ca);
   ca.Qb = (const uint4 *)lb.Qb;
   ca.Wb = (const uint4 *)Wb;
   ca.nq = nq;
@@ -1179,10 +1353,20 @@ static int run_batch(const float *What, const _Float16 *Wb, int n, const int32_t
     ANIREC_HIP_CHECK(hipMalloc((void **)&stamps, n_waves * 32));
     ca.dbg = stamps;
   }
+  if (sp && sp->inbox_start) {  // what the earlier batches of this chain found for these rows: first candidates
+    hipLaunchKernelGGL(k_merge_inbox, dim3(nq), dim3(64), 0, s, lb.cand, lb.cnt, flags, nq, sp->row0, sp->inbox_start,
+                       sp->icnt_start);
+    hipLaunchKernelGGL(k_refresh, dim3(side_grid(nq)), dim3(64), 0, s, ca);
+    ANIREC_HIP_CHECK(hipGetLastError());
+  }
   {
     const int rc = run_super_steps(ca, n, nq, false, mode, dbg_words, stamps, n_waves, s, mid_ev, mid_pct,
-                                   theta0_dev != nullptr || theta0 > kThetaInit);
+                                   theta0_dev != nullptr || theta0 > kThetaInit, sp);
     if (rc) return rc;
+  }
+  if (sp) {  // the other chain's batches must have delivered before the re-rank merges their inbox
+    if (sp->done_ev) ANIREC_HIP_CHECK(hipEventRecord(sp->done_ev, s));
+    if (sp->wait_ev) ANIREC_HIP_CHECK(hipStreamWaitEvent(s, sp->wait_ev, 0));
   }
   RerankArgs ra;
   ra.What = What;
@@ -1196,6 +1380,9 @@ static int run_batch(const float *What, const _Float16 *Wb, int n, const int32_t
   ra.cand = lb.cand;
   ra.cnt = lb.cnt;
   ra.cnt2 = ca.cnt2;
+  ra.inbox = sp ? sp->inbox_end : nullptr;
+  ra.icnt = sp ? sp->icnt_end : nullptr;
+  ra.sym_ovf = sp ? sp->ovf : nullptr;
   ra.theta = lb.theta;
   ra.flags = flags;
   ra.out_idx = out_idx;
@@ -1282,6 +1469,7 @@ struct LanePool {
   hipEvent_t fork = nullptr;
   hipEvent_t join[kMaxLanes - 1] = {nullptr, nullptr, nullptr};
   hipEvent_t mid[kMaxLanes - 1] = {nullptr, nullptr, nullptr};  // chain l passed the stagger point of its first batch
+  hipEvent_t cand_done[ANIREC_TOPK_MAX_BATCHES] = {};  // all-pairs job: batch b's last k_cand is behind this
 };
 static LanePool g_pool;
 static std::mutex g_pool_mu;
@@ -1301,6 +1489,8 @@ static int pool_get(LanePool **out) {
     ANIREC_HIP_CHECK(hipEventCreateWithFlags(&g_pool.mid[i], hipEventDisableTiming));
   }
   ANIREC_HIP_CHECK(hipEventCreateWithFlags(&g_pool.fork, hipEventDisableTiming));
+  for (int i = 0; i < ANIREC_TOPK_MAX_BATCHES; ++i)
+    ANIREC_HIP_CHECK(hipEventCreateWithFlags(&g_pool.cand_done[i], hipEventDisableTiming));
   g_pool.device = dev;
   *out = &g_pool;
   return ANIREC_OK;
@@ -1356,6 +1546,63 @@ int anirec_cosine_topk_job_plan(int32_t nq, int32_t k, int32_t prior_auto, int32
   return ANIREC_OK;
 }
 
+// The all-pairs job's plan: the learning batch, then `main_batches` batches of EQUAL WORK — batch b streams the
+// learning batch's keys, its own and those of the later batches, so the later a batch the more rows it takes (at
+// 350 k rows in 4 batches: 54 k, 65 k, 83 k, 130 k) and the two chains finish together.  Falls back to the default
+// plan (anirec_cosine_topk_job_plan) when the job is too small to learn a prior.
+int anirec_cosine_topk_allpairs_plan(int32_t n, int32_t k, int32_t lanes, int32_t main_batches, int32_t *starts_host,
+                                     int32_t *n_batches_host, int32_t *learn_batches_host) {
+  if (!starts_host || !n_batches_host || !learn_batches_host || n < 0 || k < 1) return ANIREC_EINVAL;
+  const char *mk = getenv("ANIREC_TOPK_PRIOR_MIN_K");
+  const char *pe = getenv("ANIREC_TOPK_PRIOR");
+  const char *be = getenv("ANIREC_TOPK_SYM_BATCHES");
+  // (as many batches as leave the first, smallest one ~24 k rows — enough 256-row workgroups, cut in three key ranges,
+  // for every CU; more batches waste less on the batches' own diagonal blocks, which are computed in full)
+  if (main_batches < 1) {
+    main_batches = be ? atoi(be) : 2 * (int)((double)n / 88000.0 + 0.5);  // an even number: two chains
+    if (!be) main_batches = main_batches < 2 ? 2 : (main_batches > 8 ? 8 : main_batches);
+  }
+  const bool may_learn = k >= (mk ? atoi(mk) : 32) && !(pe && atoi(pe) == 0);
+  // (below ~130 k rows the shortcut saves less than its extra launches cost: measured 4.7 vs 4.6 ms at 100 k rows,
+  // 11.1 vs 12.9 ms at 200 k, 24-25 vs 31.5 ms at 350 k, k = 100)
+  if (!may_learn || n < 131072 || main_batches < 2 || main_batches + 1 > ANIREC_TOPK_MAX_BATCHES)
+    return anirec_cosine_topk_job_plan(n, k, 1, 0, lanes, starts_host, n_batches_host, learn_batches_host);
+  const double k0 = 16384.0, rest = (double)n - k0;
+  double lo = 0.0, hi = rest * (double)n;
+  double r[ANIREC_TOPK_MAX_BATCHES];
+  for (int it = 0; it < 100; ++it) {
+    const double w = 0.5 * (lo + hi);
+    double later = 0.0;
+    for (int b = main_batches - 1; b >= 0; --b) {
+      const double c = k0 + later;
+      r[b] = 0.5 * (-c + sqrt(c * c + 4.0 * w));
+      later += r[b];
+    }
+    if (later < rest)
+      lo = w;
+    else
+      hi = w;
+  }
+  starts_host[0] = 0;
+  starts_host[1] = 16384;
+  int q0 = 16384;
+  for (int b = 0; b < main_batches; ++b) {
+    int rows = ((int)(r[b] + 0.5) + 255) / 256 * 256;
+    if (rows < 256) rows = 256;
+    if ((size_t)rows * kCap * 8 >= ((size_t)1 << 32)) return ANIREC_EINVAL;
+    q0 = (b + 1 == main_batches || q0 + rows >= n) ? n : q0 + rows;
+    starts_host[2 + b] = q0;
+    if (q0 == n && b + 1 < main_batches) {  // (rounding used the rows up early)
+      main_batches = b + 1;
+      break;
+    }
+  }
+  if ((size_t)(n - starts_host[main_batches]) * kCap * 8 >= ((size_t)1 << 32)) return ANIREC_EINVAL;
+  *n_batches_host = main_batches + 1;
+  *learn_batches_host = 1;
+  return ANIREC_OK;
+}
+
 static int max_batch_rows(const int32_t *starts, int nb) {
   int m = 0;
   for (int b = 0; b < nb; ++b) m = starts[b + 1] - starts[b] > m ? starts[b + 1] - starts[b] : m;
@@ -1368,6 +1615,22 @@ size_t anirec_cosine_topk_job_workspace_bytes(int32_t n, int32_t max_batch_rows_
   return al256(padded_keys(n) * 256) + 256 + (size_t)lanes * lane_bytes((size_t)max_batch_rows_);
 }
 
+// all-pairs mode (prior_mode 3): + two inboxes of n rows (entries, slot counters)
+static size_t inbox_bytes(size_t n) { return 2 * al256(n * kInbox * 8) + 2 * al256(n * 4); }
+// a chain's logs: one per wave of its largest launch (32 rows per wave, up to kMaxSplit key ranges)
+static size_t log_waves(size_t rows) { return (rows + 127) / 128 * 4 * kMaxSplit; }
+static size_t log_bytes(size_t rows) { return al256(log_waves(rows) * kLogCap * 16) + al256(log_waves(rows) * 4); }
+size_t anirec_cosine_topk_allpairs_workspace_bytes(int32_t n, int32_t max_batch_rows_, int32_t lanes) {
+  const size_t base = anirec_cosine_topk_job_workspace_bytes(n, max_batch_rows_, lanes);
+  return base ? base + inbox_bytes((size_t)n) + (size_t)lanes * log_bytes((size_t)max_batch_rows_) : 0;
+}
+
+// queries[i] == i for every i, or *bad = 1 (the all-pairs shortcut is only valid for the identity)
+__global__ void k_check_identity(const int32_t *queries, int nq, int32_t *bad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nq && queries[i] != i) *bad = 1;
+}
+
 int anirec_cosine_topk_job(const float *What, int32_t n, const int32_t *queries, int32_t nq, const uint8_t *keep,
                            int32_t exclude_self, int32_t k, int32_t prior_mode, float theta0,
                            const int32_t *starts_host, int32_t n_batches, int32_t learn_batches, int32_t lanes,
@@ -1375,7 +1638,7 @@ int anirec_cosine_topk_job(const float *What, int32_t n, const int32_t *queries,
                            size_t workspace_bytes, void *stream) {
   if (!What || !queries || !out_idx || !out_score || !flags_out || !workspace || !starts_host) return ANIREC_EINVAL;
   if (n < 1 || nq < 0 || k < 1 || k > ANIREC_MAX_TOPK - 1) return ANIREC_EINVAL;
-  if (prior_mode < 0 || prior_mode > 2 || lanes < 1 || lanes > kMaxLanes) return ANIREC_EINVAL;
+  if (prior_mode < 0 || prior_mode > 3 || lanes < 1 || lanes > kMaxLanes) return ANIREC_EINVAL;
   if (prior_mode == 2 && !(theta0 >= kThetaInit && theta0 <= 1.0f)) return ANIREC_EINVAL;
   if (n_batches < 0 || n_batches > ANIREC_TOPK_MAX_BATCHES || learn_batches < 0 || learn_batches > 1 ||
       learn_batches > n_batches)
@@ -1384,18 +1647,54 @@ int anirec_cosine_topk_job(const float *What, int32_t n, const int32_t *queries,
   if (starts_host[0] != 0 || starts_host[n_batches] != nq) return ANIREC_EINVAL;
   for (int b = 0; b < n_batches; ++b)
     if (starts_host[b + 1] <= starts_host[b]) return ANIREC_EINVAL;
+  // all-pairs mode: every key row is a query row, in order; it needs the learnt prior, whole key tiles per batch and
+  // at most two chains (an inbox per chain) — anything else runs as mode 1, with the same results
+  bool sym = prior_mode == 3;
+  if (sym) {
+    prior_mode = 1;
+    if (nq != n || keep != nullptr || learn_batches != 1 || n_batches < 3 || lanes > 2) sym = false;
+    for (int b = 1; sym && b < n_batches; ++b)
+      if (starts_host[b] % kBN != 0) sym = false;
+    const char *se = getenv("ANIREC_TOPK_SYM");
+    if (se && atoi(se) == 0) sym = false;
+    const char *dbg0 = getenv("ANIREC_TOPK_DEBUG");
+    if (dbg0 && atoi(dbg0) != 0) sym = false;
+  }
   if (prior_mode != 1) learn_batches = 0;
   const int rows = max_batch_rows(starts_host, n_batches);
   if (g_time_cand) lanes = 1;  // the roofline leg times k_cand launches that run alone
   if (n_batches - learn_batches < lanes) lanes = n_batches - learn_batches > 0 ? n_batches - learn_batches : 1;
-  if (workspace_bytes < anirec_cosine_topk_job_workspace_bytes(n, rows, lanes)) return ANIREC_EWORKSPACE;
+  const size_t ws_base = anirec_cosine_topk_job_workspace_bytes(n, rows, lanes);
+  if (workspace_bytes < ws_base + (sym ? inbox_bytes((size_t)n) + (size_t)lanes * log_bytes((size_t)rows) : 0))
+    return ANIREC_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   LanePool *pool = nullptr;
-  if (lanes > 1) {
+  if (lanes > 1 || sym) {
     const int rc = pool_get(&pool);
     if (rc) return rc;
   }
   char *p = (char *)workspace;
+  uint2 *inbox[2] = {nullptr, nullptr};
+  int32_t *icnt[2] = {nullptr, nullptr};
+  uint4 *logs[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+  int32_t *logcnts[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+  if (sym) {
+    char *q = p + ws_base;
+    for (int par = 0; par < 2; ++par) {
+      inbox[par] = (uint2 *)q;
+      q += al256((size_t)n * kInbox * 8);
+    }
+    for (int par = 0; par < 2; ++par) {
+      icnt[par] = (int32_t *)q;
+      q += al256((size_t)n * 4);
+    }
+    for (int l = 0; l < lanes; ++l) {
+      logs[l] = (uint4 *)q;
+      q += al256(log_waves((size_t)rows) * kLogCap * 16);
+      logcnts[l] = (int32_t *)q;
+      q += al256(log_waves((size_t)rows) * 4);
+    }
+  }
   _Float16 *Wb = (_Float16 *)p;
   p += al256(padded_keys(n) * 256);
   char *misc = p;
@@ -1409,6 +1708,12 @@ int anirec_cosine_topk_job(const float *What, int32_t n, const int32_t *queries,
   ANIREC_HIP_CHECK(hipMemsetAsync(misc, 0, 256, s));
   hipLaunchKernelGGL(k_to_f16, dim3(b1), dim3(256), 0, s, What, nullptr, n, (int)padded_keys(n), keep, 0, Wb, unnorm);
   ANIREC_HIP_CHECK(hipGetLastError());
+  if (sym) {
+    ANIREC_HIP_CHECK(hipMemsetAsync(icnt[0], 0, 2 * al256((size_t)n * 4), s));
+    // a query list that is not the identity flags every row (the `unnorm` word: rows fall to the caller's exact path)
+    hipLaunchKernelGGL(k_check_identity, dim3((nq + 255) / 256), dim3(256), 0, s, queries, nq, unnorm);
+    ANIREC_HIP_CHECK(hipGetLastError());
+  }
   const float th_imm = prior_mode == 2 ? theta0 : kThetaInit;
   const float *th_dev = nullptr;
   int b = 0;
@@ -1440,9 +1745,31 @@ int anirec_cosine_topk_job(const float *What, int32_t n, const int32_t *queries,
       if (l > 0) ANIREC_HIP_CHECK(hipStreamWaitEvent(st, pool->mid[l - 1], 0));
       if (l + 1 < lanes && i + 1 < n_batches - learn_batches) mid = pool->mid[l];
     }
+    SymPlan sp;
+    if (sym) {
+      // batch i streams the learning batch's keys, its own, and those of the later batches (all-pairs launches);
+      // the keys of the batches between arrive through the inboxes: parity = chain of the writer
+      const int par = i & 1;
+      sp.map_lo = starts_host[learn_batches] / kBN;
+      sp.map_skip = (q0 - starts_host[learn_batches]) / kBN;
+      sp.sym_from = b + 1 < n_batches ? sp.map_lo + cnt / kBN : 0x7fffffff;
+      sp.row0 = q0;
+      sp.theta0_dev = th_dev;
+      sp.inbox_w = inbox[par];
+      sp.icnt_w = icnt[par];
+      sp.log = logs[l];
+      sp.logcnt = logcnts[l];
+      sp.ovf = (int32_t *)(misc + 192);
+      sp.inbox_start = i >= 2 ? inbox[par] : nullptr;
+      sp.icnt_start = icnt[par];
+      sp.inbox_end = i >= 1 ? inbox[par ^ 1] : nullptr;
+      sp.icnt_end = icnt[par ^ 1];
+      sp.done_ev = pool->cand_done[b];
+      sp.wait_ev = (i >= 1 && lanes > 1) ? pool->cand_done[b - 1] : nullptr;
+    }
     const int rc = run_batch(What, Wb, n, queries + q0, cnt, exclude_self, k, th_imm, th_dev, lb[l], unnorm, false,
                              out_idx + (size_t)q0 * k, out_score + (size_t)q0 * k, flags_out + q0, mode, nullptr, st, mid,
-                             stagger);
+                             stagger, sym ? &sp : nullptr);
     if (rc) return rc;
   }
   if (lanes > 1) {
@@ -1507,6 +1834,7 @@ int anirec_predict_topk_mfma(const float *U, const float *A, int32_t n_anime, co
                      nullptr, kThetaInit, nullptr);
   ANIREC_HIP_CHECK(hipGetLastError());
   CandArgs ca;
+  cand_defaults(ca);
   ca.Qb = (const uint4 *)Qb;
   ca.Wb = (const uint4 *)Wb;
   ca.nq = n_users;
@@ -1538,6 +1866,9 @@ int anirec_predict_topk_mfma(const float *U, const float *A, int32_t n_anime, co
   ra.cand = cand;
   ra.cnt = cnt;
   ra.cnt2 = ca.cnt2;
+  ra.inbox = nullptr;
+  ra.icnt = nullptr;
+  ra.sym_ovf = nullptr;
   ra.theta = theta;
   ra.flags = flags_out;
   ra.out_idx = out_idx;

@@ -108,8 +108,21 @@ def topk_job_plan(nq, k, prior="auto", batch=None, lanes=None):
     return [int(st[i]) for i in range(nb.value + 1)], int(nl.value), lanes
 
 
+def topk_allpairs_plan(n, k, lanes=None, main_batches=0):
+    """The library's plan of the all-pairs job (learning batch + batches of equal work): (starts, learn_batches, lanes)."""
+    lib = _lib.load()
+    st = (C.c_int32 * (_lib.TOPK_MAX_BATCHES + 1))()
+    nb, nl = C.c_int32(0), C.c_int32(0)
+    if lanes is None:
+        lanes = int(os.environ.get("ANIREC_TOPK_LANES", "2"))
+    lanes = max(1, min(2, int(lanes)))
+    _lib.check(lib.anirec_cosine_topk_allpairs_plan(int(n), int(k), lanes, int(main_batches), st, C.byref(nb), C.byref(nl)),
+               "anirec_cosine_topk_allpairs_plan")
+    return [int(st[i]) for i in range(nb.value + 1)], int(nl.value), lanes
+
+
 def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=None, fallback=True, prior="auto",
-                     cand_timing=None, lanes=None, stats=None):
+                     cand_timing=None, lanes=None, stats=None, allpairs="auto"):
     """cosine_topk on the matrix cores (fp16 MFMA candidates + exact fp32 re-rank); rows the
     kernel could not prove complete are transparently re-run through the exact kernels.
     ``What`` must hold unit-norm rows (``rownorm`` output, as at every reference call site): the MFMA error
@@ -123,6 +136,10 @@ def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=None,
     give one for the others — their 0.5 % quantile minus the error window and a margin, computed on the device —
     which spares those rows most of their ~k ln(n) early candidates.  A row whose own threshold lies below the prior
     comes out unproven and is re-run without one.  Results are identical either way.
+    ``allpairs``: when every row is a query, in order (``queries`` == arange(n), no ``keep``), and the job learns a
+    prior, a batch computes its dot products with the rows of later batches once for both sides (cosine is symmetric;
+    include/anirec.h, prior_mode 3).  "auto" checks the query list on the device; ``False`` / env ``ANIREC_TOPK_SYM=0``
+    keep every batch on the whole key stream.  Results are identical either way.
     ``cand_timing``: a dict that receives ``ms`` / ``launches`` of all MFMA candidate-kernel launches of this call
     (HIP events on their stream, every batch and re-run included; the job then runs on one chain and blocks per
     batch — bench.py only).  ``stats``: a dict that receives ``batches``, ``learn_batches``, ``lanes``, ``starts``,
@@ -146,7 +163,13 @@ def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=None,
     keep_t = None
     if keep is not None:
         keep_t = torch.as_tensor(keep, device=dev).to(torch.uint8).contiguous()
-    starts, learn, lanes = topk_job_plan(nq, k, prior, batch, lanes)
+    want_sym = (bool(allpairs) and prior == "auto" and nq == n and keep_t is None
+                and os.environ.get("ANIREC_TOPK_SYM", "1") != "0"
+                and (allpairs is True or bool(torch.equal(q, torch.arange(n, dtype=torch.int32, device=dev)))))
+    if want_sym and batch is None:
+        starts, learn, lanes = topk_allpairs_plan(n, k, lanes)
+    else:
+        starts, learn, lanes = topk_job_plan(nq, k, prior, batch, lanes)
     nb = len(starts) - 1
     if prior is None:
         mode, theta0 = 0, 0.0
@@ -156,7 +179,13 @@ def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=None,
         mode, theta0 = 2, float(prior)
     rows = max(starts[i + 1] - starts[i] for i in range(nb))
     eff_lanes = max(1, min(lanes, nb - learn))
-    ws = torch.empty(int(lib.anirec_cosine_topk_job_workspace_bytes(n, rows, eff_lanes)), dtype=torch.uint8, device=dev)
+    sym = (want_sym and mode == 1 and nb >= 3 and eff_lanes <= 2 and all(x % 128 == 0 for x in starts[1:-1]))
+    if sym:
+        mode = 3
+        ws_bytes = int(lib.anirec_cosine_topk_allpairs_workspace_bytes(n, rows, eff_lanes))
+    else:
+        ws_bytes = int(lib.anirec_cosine_topk_job_workspace_bytes(n, rows, eff_lanes))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     flags = torch.empty(nq, dtype=torch.int32, device=dev)
     st = (C.c_int32 * (nb + 1))(*starts)
     if cand_timing is not None:
@@ -168,7 +197,7 @@ def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=None,
         ms, nl = topk_mfma_timing(False)
         cand_timing["ms"] = cand_timing.get("ms", 0.0) + ms
         cand_timing["launches"] = cand_timing.get("launches", 0) + nl
-    stats.update(batches=nb, learn_batches=learn, lanes=eff_lanes, starts=starts)
+    stats.update(batches=nb, learn_batches=learn, lanes=eff_lanes, starts=starts, allpairs=sym)
     bad = torch.nonzero(flags, as_tuple=False).flatten()       # the one host sync of the job
     n_fb = 0
     if bad.numel() and mode != 0:

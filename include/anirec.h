@@ -305,12 +305,25 @@ int anirec_cosine_topk_mfma_prior(const float *What, int32_t n, const int32_t *q
  * the k-th best scores of their rows give the others a prior, computed on the device (no host round trip); 2: theta0.
  * flags[nq] as for anirec_cosine_topk_mfma: the caller re-runs flagged rows (without a prior, then through
  * anirec_cosine_topk).  Results are identical to anirec_cosine_topk whatever the plan.
+ * prior_mode 3 = mode 1 for the ALL-PAIRS job (queries[i] == i for all i < nq == n, keep == NULL; checked on the
+ * device: any other query list flags every row): cosine(i, j) == cosine(j, i), so a batch computes the dot products of
+ * its rows with the rows of LATER batches once, for both — a score that reaches the learnt prior is also dropped into
+ * the later row's inbox (through per-wave logs a side kernel deals out) — and skips the key tiles of EARLIER batches
+ * (their pairs are in its inboxes already): ~0.65 of the MFMA work at 350 k rows.  An inbox that overflows flags its row
+ * like any unproven row.  Needs the learning batch, whole 128-row key tiles per batch (the default plan has them) and lanes <= 2;
+ * otherwise the call runs as mode 1.  Results are identical either way.  Workspace:
+ * anirec_cosine_topk_allpairs_workspace_bytes (the job's + two inboxes of n x 256 entries + the chains' logs).
  * anirec_cosine_topk_job_plan fills the library's default plan: starts_host[ANIREC_TOPK_MAX_BATCHES + 1];
  * max_batch <= 0 and lanes <= 0 select the defaults (131072 rows; env ANIREC_TOPK_LANES or 2).
  * workspace: anirec_cosine_topk_job_workspace_bytes(n, rows of the largest batch, lanes). */
 int anirec_cosine_topk_job_plan(int32_t nq, int32_t k, int32_t prior_auto, int32_t max_batch, int32_t lanes,
                                 int32_t *starts_host, int32_t *n_batches_host, int32_t *learn_batches_host);
 size_t anirec_cosine_topk_job_workspace_bytes(int32_t n, int32_t max_batch_rows, int32_t lanes);
+size_t anirec_cosine_topk_allpairs_workspace_bytes(int32_t n, int32_t max_batch_rows, int32_t lanes);
+/* the all-pairs plan: the learning batch + `main_batches` (<= 0: env ANIREC_TOPK_SYM_BATCHES or 4) batches of equal
+ * WORK (a later batch streams fewer keys and takes more rows); the default plan when the job is too small to learn */
+int anirec_cosine_topk_allpairs_plan(int32_t n, int32_t k, int32_t lanes, int32_t main_batches, int32_t *starts_host,
+                                     int32_t *n_batches_host, int32_t *learn_batches_host);
 int anirec_cosine_topk_job(const float *What, int32_t n, const int32_t *queries, int32_t nq, const uint8_t *keep,
                            int32_t exclude_self, int32_t k, int32_t prior_mode, float theta0,
                            const int32_t *starts_host, int32_t n_batches, int32_t learn_batches, int32_t lanes,

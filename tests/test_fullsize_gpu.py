@@ -134,8 +134,9 @@ def test_350k_neighbour_lists_properties_and_sample_equals_exact_path():
 
 
 def test_350k_allpairs_top100_rows_of_every_batch_equal_the_exact_path():
-    """BASELINE configs[3] users job exactly as bench.py runs it (350 k x 350 k, k = 100, the library's default plan:
-    a 16 384-row learning batch, then prior batches on two interleaved chains; similar_users.py:290-312 for every user).
+    """BASELINE configs[3] users job exactly as bench.py runs it (350 k x 350 k, k = 100, the library's all-pairs plan:
+    a 16 384-row learning batch, then batches of equal work on two interleaved chains, each computing its dot products
+    with the rows of later batches once for both sides; similar_users.py:290-312 for every user).
     Rows drawn from EVERY batch — first / last row of each, a random sample of each, and rows that come out unproven
     under the learnt prior and are re-run without it — must equal the exact kernels' lists bit for bit.
     The bulk of the table lives (almost) in a 64-dimensional subspace (k-th best cosine ~0.43); 360 planted rows are
@@ -146,7 +147,7 @@ def test_350k_allpairs_top100_rows_of_every_batch_equal_the_exact_path():
     n, k = N_USERS, 100
     W = torch.randn(n, 128, generator=g, device="cuda") * 0.05
     W[:, 64:] *= 0.04
-    st0, learn0, _ = ops.topk_job_plan(n, k)
+    st0, learn0, _ = ops.topk_allpairs_plan(n, k)
     assert learn0 == 1 and st0[1] == 16384 and len(st0) >= 5
     planted = torch.cat([torch.arange(100, 140), torch.arange(st0[1] + 7, st0[1] + 87),
                          torch.arange(st0[2] - 40, st0[2] + 40), torch.arange(st0[3] + 1000, st0[3] + 1080),
@@ -157,7 +158,7 @@ def test_350k_allpairs_top100_rows_of_every_batch_equal_the_exact_path():
     stats = {}
     idx, sim, nfb = ops.cosine_topk_mfma(Wh, q, k, stats=stats)
     starts = stats["starts"]
-    assert starts == st0 and stats["learn_batches"] == 1 and stats["lanes"] == 2
+    assert starts == st0 and stats["learn_batches"] == 1 and stats["lanes"] == 2 and stats["allpairs"] is True
     late = planted[planted >= starts[1]]
     assert stats["rerun_rows"] >= late.numel()            # every planted row behind the learning batch was refuted
     assert stats["rerun_rows"] < 2000 and nfb <= 4
@@ -173,6 +174,12 @@ def test_350k_allpairs_top100_rows_of_every_batch_equal_the_exact_path():
     # whole-job properties
     assert bool((idx >= 0).all()) and bool((idx != q[:, None]).all())
     assert bool((sim[:, 1:] <= sim[:, :-1]).all())
+    # the plain job (every batch on the whole key stream, the default plan): the same lists, row for row
+    st2 = {}
+    i2, s2, _ = ops.cosine_topk_mfma(Wh, q, k, allpairs=False, stats=st2)
+    assert st2["allpairs"] is False and st2["starts"] == ops.topk_job_plan(n, k)[0]
+    assert torch.equal(i2, idx) and torch.equal(s2, sim)
+    del i2, s2
     # one chain instead of two, and no prior at all: the same lists
     i1, s1, _ = ops.cosine_topk_mfma(Wh, q[: starts[2]], k, lanes=1)
     assert torch.equal(i1, idx[: starts[2]]) and torch.equal(s1, sim[: starts[2]])

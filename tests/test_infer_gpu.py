@@ -397,3 +397,44 @@ def test_job_lanes_give_identical_lists(lanes):
         assert torch.equal(idx, ref[0]) and torch.equal(sim, ref[1]) and nfb == ref[2]
     ei, es = ops.cosine_topk(Wh, q[:300], k)
     assert torch.equal(ref[0][:300], ei) and torch.equal(ref[1][:300], es)
+
+
+@pytest.mark.parametrize("data", ["random", "clustered"])
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_allpairs_symmetric_schedule_gives_the_plain_lists(data, lanes):
+    """Every row a query, in order: a batch computes its dot products with the rows of later batches once for both
+    sides (scores that reach the learnt prior also go to the later row's inbox) and skips the key tiles of earlier
+    batches (include/anirec.h, prior_mode 3).  The lists must be those of the plain job and of the exact path on rows
+    of every batch.  Clustered rows (260 members per cluster, cosine ~0.9 inside) push more pairs over the prior than
+    an inbox holds: those rows are flagged, re-run without the shortcut, and still right.  A query list that is not
+    the identity must not take the shortcut (checked on the device when forced)."""
+    from anime_recommendations_amd import ops
+    rng = np.random.default_rng(41)
+    n, k = 52_000, 100
+    if data == "random":
+        W = rng.normal(0, 0.05, (n, 128))
+    else:
+        centres = rng.normal(0, 1, (200, 128))
+        W = centres[rng.permutation(n) % 200] + 0.3 * rng.normal(0, 1, (n, 128))
+    Wh = ops.rownorm(torch.from_numpy(W.astype(np.float32)))
+    q = torch.arange(n, dtype=torch.int32, device="cuda")
+    st0, st1 = {}, {}
+    i0, s0, f0 = ops.cosine_topk_mfma(Wh, q, k, batch=16384, lanes=lanes, allpairs=False, stats=st0)
+    i1, s1, f1 = ops.cosine_topk_mfma(Wh, q, k, batch=16384, lanes=lanes, stats=st1)
+    assert st0["allpairs"] is False and st1["allpairs"] is True and st1["batches"] == 4 and st1["learn_batches"] == 1
+    assert torch.equal(i0, i1) and torch.equal(s0, s1)
+    if data == "random":
+        assert st1["rerun_rows"] <= 0.02 * n and f1 == 0
+    starts = st1["starts"]
+    probe = np.unique(np.concatenate([np.arange(s_, min(s_ + 100, n)) for s_ in starts[:-1]] +
+                                     [np.arange(n - 100, n), np.arange(0, n, 523)]))
+    probe = torch.from_numpy(probe).cuda()
+    ei, es = ops.cosine_topk(Wh, probe.to(torch.int32), k)
+    assert torch.equal(i1[probe], ei) and torch.equal(s1[probe], es)
+    if data == "random" and lanes == 2:
+        # forced on a permuted query list: the device check flags every row, the exact path answers
+        qp = torch.from_numpy(rng.permutation(n).astype(np.int32)).cuda()
+        st2 = {}
+        i2, s2, f2 = ops.cosine_topk_mfma(Wh, qp, k, batch=16384, lanes=lanes, allpairs=True, stats=st2)
+        assert st2["allpairs"] is True
+        assert torch.equal(i2, i0[qp.long()]) and torch.equal(s2, s0[qp.long()])
