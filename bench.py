@@ -295,8 +295,9 @@ def _cosine_leg(W, nq, k, cpu_baseline, reps=3, slice_note=None, traffic_name=No
     from anime_recommendations_amd import ops
     n = W.shape[0]
     q = torch.arange(nq, dtype=torch.int32, device="cuda")
-    Wh = ops.rownorm(W)
-    ops.cosine_topk_mfma(Wh, q, k)
+    for _ in range(2):   # (twice: the caching allocator only reaches its steady state of blocks — workspace, two
+        Wh = ops.rownorm(W)   # live output pairs — on the second call; a hipMalloc inside the timed region costs ms)
+        idx, sim, nfb = ops.cosine_topk_mfma(Wh, q, k)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     stats = {}
@@ -313,12 +314,20 @@ def _cosine_leg(W, nq, k, cpu_baseline, reps=3, slice_note=None, traffic_name=No
     ops.cosine_topk_mfma(Wh, q, k, cand_timing=acc)
     cand_ms, cand_launches = acc.get("ms", 0.0), acc.get("launches", 0)
     tfk = flops / (cand_ms * 1e-3) / 1e12
+    # all-pairs job (every key row a query row): a batch computes its dot products with the rows of later batches once
+    # for both sides and skips the key tiles of earlier batches — the share of the 2 nq n D flops the MFMA kernel executes
+    allpairs = bool(stats.get("allpairs", False))
+    st = stats.get("starts", [0, nq])
+    work = 1.0
+    if allpairs:
+        work = sum((st[b + 1] - st[b]) * (n if b == 0 else (st[1] + n - st[b])) for b in range(len(st) - 1)) / float(nq) / n
     # HBM bytes of all k_cand launches of ONE call of the profiled run (scripts/time_topk.py makes 3 calls of the same
     # job: n keys, nq queries, k)
     traffic = None
     if traffic_name:       # both instantiations (256- / 128-row workgroups: the learning batch and small jobs use the latter)
         parts = [pmc_traffic(traffic_name[0], [kern], source=["anirec_topk_mfma.hip", "ops.py"], calls=3)
-                 for kern in ("k_cand<0, 8, false>", "k_cand<0, 4, false>")]
+                 for kern in ("k_cand<0, 8, false, false>", "k_cand<0, 4, false, false>", "k_cand<0, 8, false, true>",
+                              "k_cand<0, 4, false, true>")]
         if any(p is not None for p in parts):
             traffic = sum(p for p in parts if p is not None)
     if traffic is not None and nq != traffic_name[1]:
@@ -326,12 +335,20 @@ def _cosine_leg(W, nq, k, cpu_baseline, reps=3, slice_note=None, traffic_name=No
     rec = {"value": nq / dt, "unit": "queries/s", "ms": dt * 1e3, "k": k, "n_keys": n, "n_queries": nq,
            "fallback_rows": int(nfb), "rerun_rows": int(stats.get("rerun_rows", 0)),
            "batches": int(stats.get("batches", 0)), "learn_batches": int(stats.get("learn_batches", 0)),
-           "chains": int(stats.get("lanes", 1)), "pipeline_tflops": flops / dt / 1e12,
+           "chains": int(stats.get("lanes", 1)), "allpairs_shortcut": allpairs, "pipeline_tflops": flops / dt / 1e12,
            "roofline": {"kernel": "k_cand (v_mfma_f32_16x16x32_f16 scores + fused candidate filter), "
                                   "%d launches summed" % cand_launches,
                         "bound": "mfma", "achieved": tfk, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": tfk / MFMA_F16_PEAK_TFLOPS, "kernel_ms": cand_ms,
                         "pipeline_frac": flops / dt / 1e12 / MFMA_F16_PEAK_TFLOPS, "traffic": traffic}}
+    if allpairs:
+        rec["roofline"].update({
+            "executed_flops_share": work, "executed_tflops": tfk * work,
+            "executed_frac": tfk * work / MFMA_F16_PEAK_TFLOPS,
+            "note": "`achieved` / `frac` are on the ALGORITHMIC flops of SURVEY 8(d) (2 nq n D, symmetry not exploited); "
+                    "the all-pairs job computes cosine(i, j) once for both rows across query batches, so the MFMA "
+                    "kernel executes executed_flops_share of them (executed_*): lists bit-identical to the exact "
+                    "path and to the plain job (ANIREC_TOPK_SYM=0), which the tests compare row for row"})
     if slice_note:
         rec["note"] = slice_note
     if cpu_baseline:
