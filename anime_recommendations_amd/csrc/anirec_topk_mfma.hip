@@ -1050,6 +1050,9 @@ struct SymPlan {
   hipEvent_t wait_ev;    // the previous batch's done_ev (other chain), or null
 };
 
+// a chain's logs: one per wave of its largest launch (32 rows per wave, up to kMaxSplit key ranges)
+static size_t log_waves(size_t rows) { return (rows + 255) / 256 * 8 * kMaxSplit; }  // (>= ceil(rows / 128) * 4 too)
+
 static void cand_defaults(CandArgs &ca) {
   ca.map_lo = 0x7fffffff;
   ca.map_skip = 0;
@@ -1172,6 +1175,7 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
     }
     if (sym) {
       const size_t lw = (size_t)grid2.x * grid2.y * (wide ? 8 : 4);
+      if (lw > log_waves((size_t)nq)) return ANIREC_EINVAL;  // (cannot happen: the workspace was sized by the same formula)
       (void)hipMemsetAsync(ca.logcnt, 0, lw * 4, s);  // (workgroups of an empty split write nothing)
       if (wide)
         hipLaunchKernelGGL((k_cand<0, 8, false, true>), grid2, block, 0, s, ca);
@@ -1546,6 +1550,10 @@ int anirec_cosine_topk_job_plan(int32_t nq, int32_t k, int32_t prior_auto, int32
   return ANIREC_OK;
 }
 
+// (Measured and dropped: the batch's OWN block as a triangle too — a row block starts its stream at its diagonal tile
+// and logs the pairs with the batch's later rows, merged by the re-rank from the batch's own inbox: 0.55 instead of 0.61
+// of the flops, and 25.2-26.0 ms against 24.5-25.0 for 4-10 batches: the own-block launches then run as the dearer
+// all-pairs instantiation, with workgroups of very different stream lengths.)
 // The all-pairs job's plan: the learning batch, then `main_batches` batches of EQUAL WORK — batch b streams the
 // learning batch's keys, its own and those of the later batches, so the later a batch the more rows it takes (at
 // 350 k rows in 4 batches: 54 k, 65 k, 83 k, 130 k) and the two chains finish together.  Falls back to the default
@@ -1617,8 +1625,6 @@ size_t anirec_cosine_topk_job_workspace_bytes(int32_t n, int32_t max_batch_rows_
 
 // all-pairs mode (prior_mode 3): + two inboxes of n rows (entries, slot counters)
 static size_t inbox_bytes(size_t n) { return 2 * al256(n * kInbox * 8) + 2 * al256(n * 4); }
-// a chain's logs: one per wave of its largest launch (32 rows per wave, up to kMaxSplit key ranges)
-static size_t log_waves(size_t rows) { return (rows + 127) / 128 * 4 * kMaxSplit; }
 static size_t log_bytes(size_t rows) { return al256(log_waves(rows) * kLogCap * 16) + al256(log_waves(rows) * 4); }
 size_t anirec_cosine_topk_allpairs_workspace_bytes(int32_t n, int32_t max_batch_rows_, int32_t lanes) {
   const size_t base = anirec_cosine_topk_job_workspace_bytes(n, max_batch_rows_, lanes);

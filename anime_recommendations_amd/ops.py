@@ -200,6 +200,9 @@ def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=None,
     stats.update(batches=nb, learn_batches=learn, lanes=eff_lanes, starts=starts, allpairs=sym)
     bad = torch.nonzero(flags, as_tuple=False).flatten()       # the one host sync of the job
     n_fb = 0
+    if bad.numel():     # diagnostics: how many rows carry each flag bit (1 overflow, 2 unproven, 4 not unit-norm)
+        fb = flags[bad]
+        stats["flag_rows"] = {bit: int(((fb & bit) != 0).sum()) for bit in (1, 2, 4)}
     if bad.numel() and mode != 0:
         # rows the prior was too high for (or otherwise unproven): once more without it
         sub = {}
