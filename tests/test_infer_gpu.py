@@ -438,3 +438,29 @@ def test_allpairs_symmetric_schedule_gives_the_plain_lists(data, lanes):
         i2, s2, f2 = ops.cosine_topk_mfma(Wh, qp, k, batch=16384, lanes=lanes, allpairs=True, stats=st2)
         assert st2["allpairs"] is True
         assert torch.equal(i2, i0[qp.long()]) and torch.equal(s2, s0[qp.long()])
+
+
+def test_allpairs_equal_work_plan_with_a_ragged_last_batch():
+    """The all-pairs plan proper (n >= 131 072: a learning batch + batches of equal work, the LAST one the largest)
+    with a last batch of 256 m + 1..128 rows — its launches then have one 256-row workgroup more than ceil(rows / 128)
+    / 2 (the chains' log buffers once were sized by the latter).  Lists equal the plain job's and the exact path's."""
+    from anime_recommendations_amd import ops
+    k = 40
+    n = next(m for m in range(140_000, 141_000)
+             if 0 < (m - ops.topk_allpairs_plan(m, k)[0][-2]) % 256 <= 128)
+    starts, learn, _ = ops.topk_allpairs_plan(n, k)
+    sizes = np.diff(starts)
+    assert learn == 1 and len(starts) >= 4 and sizes[-1] == sizes.max() and all(s_ % 128 == 0 for s_ in starts[1:-1])
+    g = torch.Generator(device="cuda")
+    g.manual_seed(51)
+    Wh = ops.rownorm(torch.randn(n, 128, generator=g, device="cuda") * 0.05)
+    q = torch.arange(n, dtype=torch.int32, device="cuda")
+    st = {}
+    i1, s1, f1 = ops.cosine_topk_mfma(Wh, q, k, stats=st)
+    assert st["allpairs"] is True and st["starts"] == starts and f1 == 0 and st["rerun_rows"] <= 0.02 * n
+    i0, s0, _ = ops.cosine_topk_mfma(Wh, q, k, allpairs=False)
+    assert torch.equal(i0, i1) and torch.equal(s0, s1)
+    probe = torch.from_numpy(np.unique(np.concatenate([np.arange(s_, min(s_ + 64, n)) for s_ in starts[:-1]] +
+                                                      [np.arange(n - 64, n)]))).cuda()
+    ei, es = ops.cosine_topk(Wh, probe.to(torch.int32), k)
+    assert torch.equal(i1[probe], ei) and torch.equal(s1[probe], es)
