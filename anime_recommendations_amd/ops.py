@@ -108,6 +108,29 @@ def topk_job_plan(nq, k, prior="auto", batch=None, lanes=None):
     return [int(st[i]) for i in range(nb.value + 1)], int(nl.value), lanes
 
 
+_JOB_WS = {}
+
+
+def _job_workspace(nbytes, dev):
+    """The job's workspace, kept between calls (grow-only, one per device and stream): at 350 k rows it is several GB,
+    and torch's caching allocator may carve a freed block of that size up for the next small allocations, so that the
+    following job pays a hipMalloc inside its call.  Stream-ordered reuse is safe: every job runs on torch's current
+    stream and ends joined to it.  ``release_workspaces`` drops it."""
+    key = (torch.device(dev).index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _JOB_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        _JOB_WS.pop(key, None)
+        ws = None
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        _JOB_WS[key] = ws
+    return ws
+
+
+def release_workspaces():
+    """Give the cached job workspaces back to the allocator."""
+    _JOB_WS.clear()
+
+
 def topk_allpairs_plan(n, k, lanes=None, main_batches=0):
     """The library's plan of the all-pairs job (learning batch + batches of equal work): (starts, learn_batches, lanes)."""
     lib = _lib.load()
@@ -185,7 +208,7 @@ def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=None,
         ws_bytes = int(lib.anirec_cosine_topk_allpairs_workspace_bytes(n, rows, eff_lanes))
     else:
         ws_bytes = int(lib.anirec_cosine_topk_job_workspace_bytes(n, rows, eff_lanes))
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    ws = _job_workspace(ws_bytes, dev)
     flags = torch.empty(nq, dtype=torch.int32, device=dev)
     st = (C.c_int32 * (nb + 1))(*starts)
     if cand_timing is not None:

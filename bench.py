@@ -28,6 +28,11 @@ import time
 # Python thread that launches the next GPU leg (measured: a 5.6 ms leg read 15 ms right after a baseline)
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 os.environ.setdefault("GOMP_SPINCOUNT", "0")
+# HIP multiplexes a process's streams onto 4 hardware queues by default; this process creates more than a dozen
+# (one per training engine, the cosine job's side streams), and when the job's two chains land on the SAME queue
+# they serialise: 28.0 ms instead of 24.9 for the 350 k x 350 k top-100 job (measured in this file, both ways).
+# Read by the runtime when it initialises, i.e. before the first torch.cuda call below.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 
@@ -600,7 +605,7 @@ def run_predict_topk(cpu_baseline=True):
                         "bound": "mfma", "achieved": tfk, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": tfk / MFMA_F16_PEAK_TFLOPS, "kernel_ms": cand_ms,
                         # scripts/time_predict_topk.py calls the op twice: all k_cand launches of ONE call
-                        "traffic": pmc_traffic("ptk", ["k_cand<0, 8, true>"], source="anirec_topk_mfma.hip", calls=2)}}
+                        "traffic": pmc_traffic("ptk", ["k_cand<0, 8, true, false>"], source="anirec_topk_mfma.hip", calls=2)}}
     if cpu_baseline:
         from oracle import c_oracle
         nc = 256
@@ -820,6 +825,8 @@ def main():
         if args.workload == "s109m":
             line["also"]["s109m_epoch"] = run_s109m_epoch(use_graph=not args.no_graph)
         line["also"]["cosine_topk"] = run_cosine_topk(cpu_baseline=not args.no_cpu_baseline, trained=trained)
+        from anime_recommendations_amd import ops as _ops
+        _ops.release_workspaces()      # (the all-pairs job keeps its multi-GB workspace between calls)
         line["also"]["predict_grid_100k_x_18k"] = run_predict_grid(cpu_baseline=not args.no_cpu_baseline)
         line["also"]["predict_topk_100k_users_x_18k"] = run_predict_topk(cpu_baseline=not args.no_cpu_baseline)
         line["also"]["embed_fwd_gather_4M_pairs"] = run_gather_roofline()
