@@ -420,7 +420,7 @@ def test_allpairs_symmetric_schedule_gives_the_plain_lists(data, lanes):
     q = torch.arange(n, dtype=torch.int32, device="cuda")
     st0, st1 = {}, {}
     i0, s0, f0 = ops.cosine_topk_mfma(Wh, q, k, batch=16384, lanes=lanes, allpairs=False, stats=st0)
-    i1, s1, f1 = ops.cosine_topk_mfma(Wh, q, k, batch=16384, lanes=lanes, stats=st1)
+    i1, s1, f1 = ops.cosine_topk_mfma(Wh, q, k, batch=16384, lanes=lanes, allpairs=True, stats=st1)   # ("auto": from 131 072 rows)
     assert st0["allpairs"] is False and st1["allpairs"] is True and st1["batches"] == 4 and st1["learn_batches"] == 1
     assert torch.equal(i0, i1) and torch.equal(s0, s1)
     if data == "random":
@@ -464,3 +464,24 @@ def test_allpairs_equal_work_plan_with_a_ragged_last_batch():
                                                       [np.arange(n - 64, n)]))).cuda()
     ei, es = ops.cosine_topk(Wh, probe.to(torch.int32), k)
     assert torch.equal(i1[probe], ei) and torch.equal(s1[probe], es)
+
+
+def test_allpairs_pilot_keeps_dense_tables_on_the_plain_job():
+    """Rows with far more than k neighbours above the job's prior (clusters of 1 000 at k = 50) would overflow the
+    all-pairs inboxes and be re-run: the pilot (512 sample rows against a 32 768-row sample) sees it and the job runs
+    the plain schedule; a table of small clusters (150) takes the shortcut.  The lists are the exact path's either way."""
+    from anime_recommendations_amd import ops
+    n, k = 140_032, 50
+    g = torch.Generator(device="cuda")
+    g.manual_seed(61)
+    q = torch.arange(n, dtype=torch.int32, device="cuda")
+    for csize, expect in ((1000, False), (150, True)):
+        centres = torch.randn(n // csize, 128, generator=g, device="cuda")
+        assign = torch.randperm(n, generator=g, device="cuda") % (n // csize)
+        Wh = ops.rownorm(centres[assign] + 0.3 * torch.randn(n, 128, generator=g, device="cuda"))
+        st = {}
+        idx, sim, _ = ops.cosine_topk_mfma(Wh, q, k, stats=st)
+        assert st["pilot"]["allpairs"] is expect and st["allpairs"] is expect, st["pilot"]
+        probe = torch.arange(0, n, 997, dtype=torch.int32, device="cuda")
+        ei, es = ops.cosine_topk(Wh, probe, k)
+        assert torch.equal(idx[probe.long()], ei) and torch.equal(sim[probe.long()], es)
