@@ -1573,9 +1573,9 @@ int anirec_cosine_topk_allpairs_plan(int32_t n, int32_t k, int32_t lanes, int32_
   // (the plain job learns a prior from k = 32 on; here the prior is what makes the shortcut possible, and it pays at
   // k = 10 too: 350 k x 350 k top-10 28.3 -> 18.8 ms)
   const bool may_learn = k >= (mk ? atoi(mk) : 8) && !(pe && atoi(pe) == 0);
-  // (below ~130 k rows the shortcut saves less than its extra launches cost: measured 4.7 vs 4.6 ms at 100 k rows,
-  // 11.1 vs 12.9 ms at 200 k, 24-25 vs 31.5 ms at 350 k, k = 100)
-  if (!may_learn || n < 131072 || main_batches < 2 || main_batches + 1 > ANIREC_TOPK_MAX_BATCHES)
+  // (below ~200 k rows the shortcut saves less than its extra launches and the caller's pilot cost: measured 4.7 vs
+  // 4.6 ms at 100 k rows, 8.6 vs 8.2 at 150 k, 10.3-15.8 vs 12.6-17.3 at 222 k, 24-25 vs 31.5 ms at 350 k)
+  if (!may_learn || n < 196608 || main_batches < 2 || main_batches + 1 > ANIREC_TOPK_MAX_BATCHES)
     return anirec_cosine_topk_job_plan(n, k, 1, 0, lanes, starts_host, n_batches_host, learn_batches_host);
   const double k0 = 16384.0, rest = (double)n - k0;
   double lo = 0.0, hi = rest * (double)n;

@@ -216,10 +216,10 @@ def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=None,
     keep_t = None
     if keep is not None:
         keep_t = torch.as_tensor(keep, device=dev).to(torch.uint8).contiguous()
-    # (below 131 072 rows the all-pairs plan is the default plan and the shortcut buys nothing: no device check, no sync)
+    # (below 196 608 rows the all-pairs plan is the default plan and the shortcut buys nothing: no device check, no sync)
     want_sym = (bool(allpairs) and prior == "auto" and nq == n and keep_t is None
                 and os.environ.get("ANIREC_TOPK_SYM", "1") != "0"
-                and (allpairs is True or (n >= 131072
+                and (allpairs is True or (n >= 196608
                                           and bool(torch.equal(q, torch.arange(n, dtype=torch.int32, device=dev))))))
     if want_sym and allpairs == "auto" and os.environ.get("ANIREC_TOPK_PILOT", "1") != "0":
         want_sym = _allpairs_pilot(What, n, k + int(bool(exclude_self)), stats)

@@ -420,7 +420,7 @@ def test_allpairs_symmetric_schedule_gives_the_plain_lists(data, lanes):
     q = torch.arange(n, dtype=torch.int32, device="cuda")
     st0, st1 = {}, {}
     i0, s0, f0 = ops.cosine_topk_mfma(Wh, q, k, batch=16384, lanes=lanes, allpairs=False, stats=st0)
-    i1, s1, f1 = ops.cosine_topk_mfma(Wh, q, k, batch=16384, lanes=lanes, allpairs=True, stats=st1)   # ("auto": from 131 072 rows)
+    i1, s1, f1 = ops.cosine_topk_mfma(Wh, q, k, batch=16384, lanes=lanes, allpairs=True, stats=st1)   # ("auto": from 196 608 rows)
     assert st0["allpairs"] is False and st1["allpairs"] is True and st1["batches"] == 4 and st1["learn_batches"] == 1
     assert torch.equal(i0, i1) and torch.equal(s0, s1)
     if data == "random":
@@ -441,12 +441,12 @@ def test_allpairs_symmetric_schedule_gives_the_plain_lists(data, lanes):
 
 
 def test_allpairs_equal_work_plan_with_a_ragged_last_batch():
-    """The all-pairs plan proper (n >= 131 072: a learning batch + batches of equal work, the LAST one the largest)
+    """The all-pairs plan proper (n >= 196 608: a learning batch + batches of equal work, the LAST one the largest)
     with a last batch of 256 m + 1..128 rows — its launches then have one 256-row workgroup more than ceil(rows / 128)
     / 2 (the chains' log buffers once were sized by the latter).  Lists equal the plain job's and the exact path's."""
     from anime_recommendations_amd import ops
     k = 40
-    n = next(m for m in range(140_000, 141_000)
+    n = next(m for m in range(200_000, 201_000)
              if 0 < (m - ops.topk_allpairs_plan(m, k)[0][-2]) % 256 <= 128)
     starts, learn, _ = ops.topk_allpairs_plan(n, k)
     sizes = np.diff(starts)
@@ -471,7 +471,7 @@ def test_allpairs_pilot_keeps_dense_tables_on_the_plain_job():
     all-pairs inboxes and be re-run: the pilot (512 sample rows against a 32 768-row sample) sees it and the job runs
     the plain schedule; a table of small clusters (150) takes the shortcut.  The lists are the exact path's either way."""
     from anime_recommendations_amd import ops
-    n, k = 140_032, 50
+    n, k = 200_192, 50
     g = torch.Generator(device="cuda")
     g.manual_seed(61)
     q = torch.arange(n, dtype=torch.int32, device="cuda")
