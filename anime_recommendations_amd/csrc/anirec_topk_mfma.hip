@@ -4,7 +4,7 @@
 // similar_users.py:293-296) at BASELINE scale (every row a query, top-k of 18 k / 350 k rows) without
 // ever materialising the n x n score matrix.
 //
-// Three kernels:
+// Three kernels (+ k_scatter_log / k_merge_inbox of the all-pairs job, prior_mode 3):
 //   k_cand    one SUPER-STEP of the key stream: v_mfma_f32_16x16x32_f16 scores of 128 queries x a range
 //             of key tiles per workgroup (fp16 operands: the bf16 MFMA rate with 8x smaller rounding
 //             error; the 16x16x32 shape because the chip holds a higher clock on it).  Each query row
@@ -42,6 +42,10 @@
 //     then per-register tests and an LDS-staged append on a hit) to every tile of the present kernel — k_cand
 //     6.6 -> 13.5 ms at k = 100 and 5.3 -> 8.2 ms at k = 10, i.e. at best 0.98x / 1.29x after halving the tiles.
 //     Not built: the second filter costs what the saved MFMAs are worth.
+//     (Round 3 built it WITHOUT a second filter — see CandArgs / SymPlan / anirec_cosine_topk_allpairs_plan below: the
+//     symmetry is used ACROSS query batches only, where every row of a later batch still sits at the job's learnt
+//     prior, so ONE test against the prior serves both rows; the pairs for the key's row leave through per-wave logs
+//     (k_scatter_log -> inboxes -> k_merge_inbox / the re-rank).  350 k x 350 k top-100: 31.5 -> 24.9 ms.)
 //   Where the k = 100 time goes (ANIREC_TOPK_DEBUG=16, same 65 536-query slice, same box): no filter at all 4.2 ms;
 //   the filter with thresholds nothing passes 4.4-4.5 ms; ONE launch with the FINAL thresholds handed in (a row
 //   appends only its k + window candidates) 5.0-5.6 ms; the real schedule — 11 launches, each threshold the k-th
