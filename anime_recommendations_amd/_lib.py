@@ -108,6 +108,7 @@ PROTOTYPES = {
     "anirec_trainer_run": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
     "anirec_eval": (C.c_int, [_DP, _vp, _vp, _vp, _i32, _vp]),
     "anirec_adam_flat": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _f32, _vp]),
+    "anirec_selftest_lazy_math": (C.c_int, [C.c_uint64, _vp, _vp]),
     "anirec_gather_ratings": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "anirec_rownorm": (C.c_int, [_vp, _i32, _vp, _vp]),
     "anirec_cosine_scores": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),

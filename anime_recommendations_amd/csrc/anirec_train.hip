@@ -1231,78 +1231,129 @@ __device__ __forceinline__ float l2_only_grad(float w, float two_l2) {
 // Adam's moments live in, the scaling and fix-up steps are identities, and what is left — the residual tests and the
 // fma chain, instruction for instruction what the expansions execute — runs on PAIRS (v_pk_fma_f32 / v_pk_mul_f32 /
 // v_pk_add_f32).  A wave whose operands leave the range (a moment decayed to a denormal, an exact zero) takes the
-// compiler's path for that step: the results are the dense kernel's bit for bit either way (tested on every element
-// of the S109M tables).
+// compiler's path for that row: the results are the dense kernel's bit for bit either way (tested on every element
+// of the S109M tables; the square root is compared with sqrtf on EVERY float of its range, anirec_selftest_lazy_math).
+//
+// Round 4 (PMC: the kernel issues, it does not wait — profiles/r04_pmc_valu_train_s109m.json):
+//  * the range tests left the step: every pair-step folds its second moment and |m alpha| into a running
+//    min / max (v_min3_f32 / v_max3_f32: 4 instructions instead of 8 compares + 7 s_and) and the row is tested ONCE,
+//    after its last step.  A NaN slips through min / max, but it is sticky (w NaN -> g, m, v NaN; m or v NaN -> w NaN),
+//    so one test of the final w catches it.
+//  * the +-1 ulp selection of the square root is integer arithmetic on the residuals' bit patterns
+//    (a float is > 0 exactly when its bits, read as a signed integer, are > 0: v_med3_i32(bits, 0, 1)), not
+//    v_cmp + v_cndmask through VCC: each such pair costs two wait states on gfx950 that the compiler could only
+//    half fill (494 s_nop in the round-3 kernel).
+//  * g = 2 lambda w without the "+ 0" of l2_only_grad: it only matters when the product is -0, and then the first
+//    moment of that step is +-0, |m alpha| = 0 fails the range test and the row is redone by the compiler's path.
+// The four elements of a lane are two PAIRS stepped side by side, statement by statement: every operation is two
+// independent v_pk_*_f32 back to back.  (Written as one pair after the other, hipcc ran one pair's divide chain behind
+// the other's — gfx950 wants a wait state between DEPENDENT packed-f32 instructions, and that schedule paid an s_nop
+// for each; written as one 4-wide vector, its subtractions and negations come out scalar.)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct Quad {
+  f32x2 a, b;
+};
+// (the contraction flag of an operation is the one in force where it is WRITTEN: these bodies, not their callers)
+#pragma clang fp contract(off)
+__device__ __forceinline__ Quad operator+(Quad x, Quad y) { return {x.a + y.a, x.b + y.b}; }
+__device__ __forceinline__ Quad operator-(Quad x, Quad y) { return {x.a - y.a, x.b - y.b}; }
+__device__ __forceinline__ Quad operator*(Quad x, Quad y) { return {x.a * y.a, x.b * y.b}; }
+__device__ __forceinline__ Quad operator*(Quad x, float y) { return {x.a * y, x.b * y}; }
+__device__ __forceinline__ Quad operator+(Quad x, float y) { return {x.a + y, x.b + y}; }
+__device__ __forceinline__ Quad operator-(Quad x) { return {-x.a, -x.b}; }
+#pragma clang fp contract(fast)
+__device__ __forceinline__ Quad qfma(Quad x, Quad y, Quad z) {
+  return {__builtin_elementwise_fma(x.a, y.a, z.a), __builtin_elementwise_fma(x.b, y.b, z.b)};
+}
 
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// min(max(x, 0), 1) as ONE instruction (hipcc rewrites the C expression into v_cmp + v_addc through VCC, the very
+// pattern this replaces; there is no builtin for the integer median)
+__device__ __forceinline__ int clamp01_i32(int x) {
+  int r;
+  asm("v_med3_i32 %0, %1, 0, 1" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ int f2i(float x) { return (int)__float_as_uint(x); }
+__device__ __forceinline__ float i2f(int x) { return __uint_as_float((unsigned)x); }
 
-// correctly rounded sqrt of x in [2^-96, 2^96]: v_sqrt_f32 is within 1 ulp; the residuals pick the neighbour
-__device__ __forceinline__ f32x2 sqrt_pair_normal(f32x2 x) {
-  f32x2 s, sm, sp;
-  s.x = __builtin_amdgcn_sqrtf(x.x);
-  s.y = __builtin_amdgcn_sqrtf(x.y);
-  sm.x = __uint_as_float(__float_as_uint(s.x) - 1u);
-  sm.y = __uint_as_float(__float_as_uint(s.y) - 1u);
-  sp.x = __uint_as_float(__float_as_uint(s.x) + 1u);
-  sp.y = __uint_as_float(__float_as_uint(s.y) + 1u);
-  const f32x2 r1 = pk_fma(-sm, s, x), r2 = pk_fma(-sp, s, x);
-  f32x2 res;
-  res.x = 0.f >= r1.x ? sm.x : s.x;
-  res.y = 0.f >= r1.y ? sm.y : s.y;
-  res.x = 0.f < r2.x ? sp.x : res.x;
-  res.y = 0.f < r2.y ? sp.y : res.y;
+// correctly rounded sqrt of x in [2^-96, 2^96]: v_sqrt_f32 is within 1 ulp; the residuals x - (s -+ ulp) s pick the
+// neighbour: one ulp down when the first is <= 0, one ulp up when the second is > 0 (never both)
+__device__ __forceinline__ Quad sqrt4_normal(Quad x) {
+  Quad s, sm, sp;
+  s.a.x = __builtin_amdgcn_sqrtf(x.a.x);
+  s.a.y = __builtin_amdgcn_sqrtf(x.a.y);
+  s.b.x = __builtin_amdgcn_sqrtf(x.b.x);
+  s.b.y = __builtin_amdgcn_sqrtf(x.b.y);
+  const int b0 = f2i(s.a.x), b1 = f2i(s.a.y), b2 = f2i(s.b.x), b3 = f2i(s.b.y);
+  sm.a.x = i2f(b0 - 1), sm.a.y = i2f(b1 - 1), sm.b.x = i2f(b2 - 1), sm.b.y = i2f(b3 - 1);
+  sp.a.x = i2f(b0 + 1), sp.a.y = i2f(b1 + 1), sp.b.x = i2f(b2 + 1), sp.b.y = i2f(b3 + 1);
+  const Quad r1 = qfma(-sm, s, x), r2 = qfma(-sp, s, x);
+  Quad res;
+  res.a.x = i2f((b0 - 1) + clamp01_i32(f2i(r1.a.x)) + clamp01_i32(f2i(r2.a.x)));
+  res.a.y = i2f((b1 - 1) + clamp01_i32(f2i(r1.a.y)) + clamp01_i32(f2i(r2.a.y)));
+  res.b.x = i2f((b2 - 1) + clamp01_i32(f2i(r1.b.x)) + clamp01_i32(f2i(r2.b.x)));
+  res.b.y = i2f((b3 - 1) + clamp01_i32(f2i(r1.b.y)) + clamp01_i32(f2i(r2.b.y)));
   return res;
 }
 
 // correctly rounded n / d for operands that need no v_div_scale scaling and no v_div_fixup
-__device__ __forceinline__ f32x2 div_pair_normal(f32x2 n, f32x2 d) {
+__device__ __forceinline__ Quad div4_normal(Quad n, Quad d) {
 #pragma clang fp contract(off)
-  f32x2 y0;
-  y0.x = __builtin_amdgcn_rcpf(d.x);
-  y0.y = __builtin_amdgcn_rcpf(d.y);
-  const f32x2 one = {1.0f, 1.0f};
-  const f32x2 e = pk_fma(-d, y0, one);
-  const f32x2 y = pk_fma(e, y0, y0);
-  const f32x2 q0 = n * y;
-  const f32x2 r0 = pk_fma(-d, q0, n);
-  const f32x2 q1 = pk_fma(r0, y, q0);
-  const f32x2 r1 = pk_fma(-d, q1, n);
-  return pk_fma(r1, y, q1);
+  Quad y0;
+  y0.a.x = __builtin_amdgcn_rcpf(d.a.x);
+  y0.a.y = __builtin_amdgcn_rcpf(d.a.y);
+  y0.b.x = __builtin_amdgcn_rcpf(d.b.x);
+  y0.b.y = __builtin_amdgcn_rcpf(d.b.y);
+  const Quad one = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+  const Quad e = qfma(-d, y0, one);
+  const Quad y = qfma(e, y0, y0);
+  const Quad q0 = n * y;
+  const Quad r0 = qfma(-d, q0, n);
+  const Quad q1 = qfma(r0, y, q0);
+  const Quad r1 = qfma(-d, q1, n);
+  return qfma(r1, y, q1);
 }
 
-__device__ __forceinline__ bool in_range(float x, float lo, float hi) { return x >= lo && x <= hi; }
+// what the short sequences are exact for: second moments in [2^-96, 2^96] (no sqrt scaling), |m alpha| in
+// [2^-60, 2^60] with the denominator sqrt(v) + 1e-7 in [1e-7, 2^48 + eps] (no v_div_scale, no v_div_fixup)
+struct LzRange {
+  float vlo, vhi, nlo, nhi;
+};
+__device__ __forceinline__ LzRange lz_range_init() { return {3.0e38f, 0.f, 3.0e38f, 0.f}; }
+__device__ __forceinline__ bool lz_range_ok(const LzRange &r) {
+  return r.vlo >= 0x1p-96f && r.vhi <= 0x1p96f && r.nlo >= 0x1p-60f && r.nhi <= 0x1p60f;
+}
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
-// one L2-only Adam step of a pair by the short sequences; returns whether every operand was inside the range they
-// are exact for (the caller discards the whole replay of the wave otherwise)
-__device__ __forceinline__ bool adam_pair_l2(f32x2 &w, f32x2 &m, f32x2 &v, float alpha, float two_l2) {
+// one L2-only Adam step of a lane's four elements by the short sequences; the operands the sequences are conditional
+// on are folded into `rg` (tested by the caller once per row)
+__device__ __forceinline__ void adam4_l2(Quad &w, Quad &m, Quad &v, float alpha, float two_l2, LzRange &rg) {
 #pragma clang fp contract(off)
-  const f32x2 g = two_l2 * w + 0.0f;
-  const f32x2 mn = m + (g - m) * kOneMinusB1;
-  const f32x2 vn = v + (g * g - v) * kOneMinusB2;
-  const f32x2 num = mn * alpha;
-  constexpr float kLo = 0x1p-60f, kHi = 0x1p60f;
-  const bool ok = in_range(vn.x, 0x1p-96f, 0x1p96f) && in_range(vn.y, 0x1p-96f, 0x1p96f) &&
-                  in_range(fabsf(num.x), kLo, kHi) && in_range(fabsf(num.y), kLo, kHi);
-  const f32x2 den = sqrt_pair_normal(vn) + kAdamEps;  // in [1e-7, 2^48 + eps]: inside the divide's range
-  w = w - div_pair_normal(num, den);
+  const Quad g = w * two_l2;
+  const Quad mn = m + (g - m) * kOneMinusB1;
+  const Quad vn = v + (g * g - v) * kOneMinusB2;
+  const Quad num = mn * alpha;
+  rg.vlo = min3f(min3f(rg.vlo, vn.a.x, vn.a.y), vn.b.x, vn.b.y);
+  rg.vhi = max3f(max3f(rg.vhi, vn.a.x, vn.a.y), vn.b.x, vn.b.y);
+  rg.nlo = min3f(min3f(rg.nlo, fabsf(num.a.x), fabsf(num.a.y)), fabsf(num.b.x), fabsf(num.b.y));
+  rg.nhi = max3f(max3f(rg.nhi, fabsf(num.a.x), fabsf(num.a.y)), fabsf(num.b.x), fabsf(num.b.y));
+  const Quad den = sqrt4_normal(vn) + kAdamEps;
+  w = w - div4_normal(num, den);
   m = mn;
   v = vn;
-  return ok;
 }
 
 template <bool kFast>
-__device__ __forceinline__ bool lazy_one_step(Row3 &x, float alpha, float two_l2, float &sq) {
+__device__ __forceinline__ void lazy_one_step(Row3 &x, float alpha, float two_l2, float &sq, LzRange &rg) {
   sq = x.w.x * x.w.x + x.w.y * x.w.y + x.w.z * x.w.z + x.w.w * x.w.w;
   if (kFast) {
-    f32x2 w0 = {x.w.x, x.w.y}, w1 = {x.w.z, x.w.w}, m0 = {x.m.x, x.m.y}, m1 = {x.m.z, x.m.w}, v0 = {x.v.x, x.v.y},
-          v1 = {x.v.z, x.v.w};
-    const bool f0 = adam_pair_l2(w0, m0, v0, alpha, two_l2);
-    const bool f1 = adam_pair_l2(w1, m1, v1, alpha, two_l2);
-    x.w = make_float4(w0.x, w0.y, w1.x, w1.y);
-    x.m = make_float4(m0.x, m0.y, m1.x, m1.y);
-    x.v = make_float4(v0.x, v0.y, v1.x, v1.y);
-    return f0 && f1;
+    Quad w = {{x.w.x, x.w.y}, {x.w.z, x.w.w}}, m = {{x.m.x, x.m.y}, {x.m.z, x.m.w}}, v = {{x.v.x, x.v.y}, {x.v.z, x.v.w}};
+    adam4_l2(w, m, v, alpha, two_l2, rg);
+    x.w = make_float4(w.a.x, w.a.y, w.b.x, w.b.y);
+    x.m = make_float4(m.a.x, m.a.y, m.b.x, m.b.y);
+    x.v = make_float4(v.a.x, v.a.y, v.b.x, v.b.y);
+    return;
   }
   // the compiler's full expansions (scaling, fix-up)
   const float gx = l2_only_grad(x.w.x, two_l2), gy = l2_only_grad(x.w.y, two_l2), gz = l2_only_grad(x.w.z, two_l2),
@@ -1311,32 +1362,36 @@ __device__ __forceinline__ bool lazy_one_step(Row3 &x, float alpha, float two_l2
   adam_elem(x.w.y, x.m.y, x.v.y, gy, alpha);
   adam_elem(x.w.z, x.m.z, x.v.z, gz, alpha);
   adam_elem(x.w.w, x.m.w, x.v.w, gw, alpha);
-  return true;
 }
 
+// returns whether the short sequences were exact for every operand of every step this lane took (kFast)
 template <bool kFast>
 __device__ __forceinline__ bool lazy_replay_path(Row3 &x, int j0, int j1, const float (&alpha)[kLzWin], float two_l2,
                                                  float (&sq)[kLzWin]) {
-  bool ok = true;
+  LzRange rg = lz_range_init();
   if (__all(j0 <= 0 && j1 >= kLzWin)) {  // the common case (a row untouched for a whole window): no predication
 #pragma unroll
-    for (int j = 0; j < kLzWin; ++j) ok &= lazy_one_step<kFast>(x, alpha[j], two_l2, sq[j]);
-    return ok;
-  }
+    for (int j = 0; j < kLzWin; ++j) lazy_one_step<kFast>(x, alpha[j], two_l2, sq[j], rg);
+  } else {
 #pragma unroll
-  for (int j = 0; j < kLzWin; ++j) {
-    if (__any(j >= j0 && j < j1)) {  // wave-uniform skip, then per-lane selection of the stepped values
-      Row3 y = x;
-      float q;
-      const bool o = lazy_one_step<kFast>(y, alpha[j], two_l2, q);
-      if (j >= j0 && j < j1) {
-        x = y;
-        sq[j] = q;
-        ok &= o;
+    for (int j = 0; j < kLzWin; ++j) {
+      if (__any(j >= j0 && j < j1)) {  // wave-uniform skip, then per-lane selection of the stepped values
+        Row3 y = x;
+        LzRange ry = rg;
+        float q;
+        lazy_one_step<kFast>(y, alpha[j], two_l2, q, ry);
+        if (j >= j0 && j < j1) {
+          x = y;
+          rg = ry;
+          sq[j] = q;
+        }
       }
     }
   }
-  return ok;
+  if (!kFast) return true;
+  if (j1 <= j0) return true;           // nothing taken (the accumulators still hold their initial values)
+  const float t = (x.w.x + x.w.y) + (x.w.z + x.w.w);  // a NaN anywhere in the replay has reached w
+  return lz_range_ok(rg) && t == t;
 }
 
 // pending pure-L2 steps [j0, j1) (window-relative) of one row, a float4 per lane; sq[j] receives this lane's part of
@@ -1661,6 +1716,64 @@ __global__ __launch_bounds__(256) void k_adam_flat(float *w, float *m, float *v,
     w[i] = ww;
     m[i] = mm;
     v[i] = vv;
+  }
+}
+
+// Self-test of the lazy replay's short sequences (anirec_selftest_lazy_math; tests only).  Square root: EVERY float
+// of the range the sequence is used on, [2^-96, 2^96], against the compiler's correctly rounded sqrtf — 1.6 x 10^9
+// inputs, exhaustive.  Divide: `n_div` pseudo-random (numerator, denominator) pairs drawn over the ranges the
+// replay admits, against the IEEE `/` (the sequence is the compiler's own Markstein chain without its scaling and
+// fix-up steps, so this is a regression guard, not the argument).  counts[0] += sqrt mismatches, counts[1] += divide
+// mismatches.
+__global__ __launch_bounds__(256) void k_selftest_lazy_math(unsigned long long n_div, unsigned long long *counts) {
+  const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long nth = (unsigned long long)gridDim.x * blockDim.x;
+  const uint32_t lo = __float_as_uint(0x1p-96f), hi = __float_as_uint(0x1p96f);
+  unsigned long long bad_s = 0, bad_d = 0;
+  for (unsigned long long b = (unsigned long long)lo + 4 * tid; b <= hi; b += 4 * nth) {
+    Quad x;
+    x.a.x = __uint_as_float((uint32_t)min(b + 0, (unsigned long long)hi));
+    x.a.y = __uint_as_float((uint32_t)min(b + 1, (unsigned long long)hi));
+    x.b.x = __uint_as_float((uint32_t)min(b + 2, (unsigned long long)hi));
+    x.b.y = __uint_as_float((uint32_t)min(b + 3, (unsigned long long)hi));
+    const Quad s = sqrt4_normal(x);
+    bad_s += __float_as_uint(s.a.x) != __float_as_uint(sqrtf(x.a.x));
+    bad_s += __float_as_uint(s.a.y) != __float_as_uint(sqrtf(x.a.y));
+    bad_s += __float_as_uint(s.b.x) != __float_as_uint(sqrtf(x.b.x));
+    bad_s += __float_as_uint(s.b.y) != __float_as_uint(sqrtf(x.b.y));
+  }
+  // numerators +-[2^-60, 2^60], denominators [1e-7, 2^48]: mantissa bits and exponent from a 64-bit mix of the index
+  auto mix = [](unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  };
+  auto draw = [&](unsigned long long h, int e_lo, int e_span, bool sign) {
+    const uint32_t man = (uint32_t)h & 0x7FFFFFu;
+    const uint32_t ex = (uint32_t)(127 + e_lo + (int)((h >> 23) % (unsigned)e_span));
+    const uint32_t sg = sign ? (uint32_t)((h >> 40) & 1u) << 31 : 0u;
+    return __uint_as_float(sg | (ex << 23) | man);
+  };
+  for (unsigned long long i = 4 * tid; i < n_div; i += 4 * nth) {
+    float nv[4], dv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned long long h1 = mix(2 * (i + k)), h2 = mix(2 * (i + k) + 1);
+      nv[k] = draw(h1, -60, 120, true);
+      dv[k] = fmaxf(draw(h2, -24, 72, false), kAdamEps);
+    }
+    const Quad n = {{nv[0], nv[1]}, {nv[2], nv[3]}}, d = {{dv[0], dv[1]}, {dv[2], dv[3]}};
+    const Quad q = div4_normal(n, d);
+    const float qs[4] = {q.a.x, q.a.y, q.b.x, q.b.y};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bad_d += __float_as_uint(qs[k]) != __float_as_uint(nv[k] / dv[k]);
+  }
+  bad_s = (unsigned long long)wave_sum_d((double)bad_s);
+  bad_d = (unsigned long long)wave_sum_d((double)bad_d);
+  if ((threadIdx.x & 63) == 0) {
+    if (bad_s) atomicAdd(counts + 0, bad_s);
+    if (bad_d) atomicAdd(counts + 1, bad_d);
   }
 }
 
@@ -2609,6 +2722,15 @@ int anirec_adam_flat(float *w, float *m, float *v, const float *g, size_t n, flo
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(k_adam_flat, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, m,
                      v, g, n, alpha);
+  return (int)hipGetLastError();
+}
+
+int anirec_selftest_lazy_math(uint64_t n_div, uint64_t *counts2, void *stream) {
+  if (!counts2) return ANIREC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ANIREC_HIP_CHECK(hipMemsetAsync(counts2, 0, 2 * sizeof(uint64_t), s));
+  hipLaunchKernelGGL(k_selftest_lazy_math, dim3(8192), dim3(256), 0, s, (unsigned long long)n_div,
+                     reinterpret_cast<unsigned long long *>(counts2));
   return (int)hipGetLastError();
 }
 

@@ -151,7 +151,7 @@ class DistTrainEngine:
         self._use_flat_gather = backend == "nccl"
         self._use_reduce_scatter = backend == "nccl"
         self._comm = None
-        if loop and backend == "nccl" and os.environ.get("ANIREC_DIST_NATIVE", "1") != "0":
+        if loop and backend == "nccl" and os.environ.get("ANIREC_DIST_NATIVE", "0") == "1":
             self._comm = self._native_comm()
         if self.mode == "replicated_rs":
             sr = self.shard_rows

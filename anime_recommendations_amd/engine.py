@@ -53,9 +53,9 @@ class TrainEngine:
         row_pad = max(1, int(row_pad))
         self.rows_alloc = (self.rows + row_pad - 1) // row_pad * row_pad
         self._Wfull = torch.zeros(self.rows_alloc, DIM, dtype=torch.float32, device=dev)
-        self.W = self._Wfull[: self.rows]
-        self.M = torch.zeros(self.rows, DIM, dtype=torch.float32, device=dev)
-        self.V = torch.zeros_like(self.M)
+        self._W = self._Wfull[: self.rows]
+        self._M = torch.zeros(self.rows, DIM, dtype=torch.float32, device=dev)
+        self._V = torch.zeros_like(self._M)
         self.rowmap = torch.zeros(2 * self.rows, dtype=torch.int32, device=dev)
         self.adam_rows = (0, 0) if adam_rows is None else (int(adam_rows[0]), int(adam_rows[1]))
         self.state_buf = _dev_bytes(_lib.STATE_DTYPE.itemsize, dev)
@@ -85,6 +85,24 @@ class TrainEngine:
         self.set_head()
 
     # ---- views ---------------------------------------------------------------------
+    # The kernels run on the engine's PRIVATE stream: a view handed out while steps are still in flight would be read
+    # by torch (on its own stream) before they have finished.  Every public view therefore waits for the engine's
+    # stream first; the kernels' own plumbing uses the raw `_W` / `_M` / `_V`.
+    @property
+    def W(self):
+        self.stream.synchronize()
+        return self._W
+
+    @property
+    def M(self):
+        self.stream.synchronize()
+        return self._M
+
+    @property
+    def V(self):
+        self.stream.synchronize()
+        return self._V
+
     @property
     def U(self):
         return self.W[: self.n_user_rows]
@@ -121,15 +139,15 @@ class TrainEngine:
         A = torch.as_tensor(A, dtype=torch.float32)
         assert U.shape == (self.n_user_rows, DIM) and A.shape == (self.n_anime_rows, DIM)
         self.stream.synchronize()
-        self.W[: self.n_user_rows].copy_(U)
-        self.W[self.n_user_rows:].copy_(A)
+        self._W[: self.n_user_rows].copy_(U)
+        self._W[self.n_user_rows:].copy_(A)
         torch.cuda.synchronize(self.device)
         self.init_reg()
 
     def reset_optimizer(self):
         self.stream.synchronize()
-        self.M.zero_()
-        self.V.zero_()
+        self._M.zero_()
+        self._V.zero_()
         torch.cuda.synchronize(self.device)
 
     def optimizer_state(self, iterations=0):
@@ -151,7 +169,7 @@ class TrainEngine:
         d.dense_rows = self.dense_rows
         d.adam_row_lo, d.adam_row_hi = self.adam_rows
         d.l2 = self.l2
-        d.W, d.M, d.V = _lib.ptr(self.W), _lib.ptr(self.M), _lib.ptr(self.V)
+        d.W, d.M, d.V = _lib.ptr(self._W), _lib.ptr(self._M), _lib.ptr(self._V)
         d.rowmap, d.state = _lib.ptr(self.rowmap), _lib.ptr(self.state_buf)
         d.user_idx, d.anime_idx = _lib.ptr(self.user_idx), _lib.ptr(self.anime_idx)
         d.rating, d.sched = _lib.ptr(self.rating), _lib.ptr(self.sched)

@@ -246,6 +246,12 @@ int anirec_eval(const anirec_train_desc *d, const int32_t *user_idx, const int32
 int anirec_adam_flat(float *w, float *m, float *v, const float *g, size_t n, float alpha,
                      void *stream);
 
+/* Self-test of the lazy update's short arithmetic sequences (tests only; no reference call site — it guards the claim
+ * that the lazy dense Adam performs the dense kernel's fp32 operations): the correctly rounded square root the replay
+ * uses is compared with sqrtf on EVERY float of [2^-96, 2^96], its divide with IEEE `/` on n_div pseudo-random operand
+ * pairs of the admitted ranges.  counts2[0] / counts2[1] (device, uint64) receive the numbers of mismatches. */
+int anirec_selftest_lazy_math(uint64_t n_div, uint64_t *counts2, void *stream);
+
 /* Epoch shuffle: out[i] = in[perm[i]] for the three rating columns (model.fit shuffle=True). */
 int anirec_gather_ratings(const int32_t *user_in, const int32_t *anime_in, const float *rating_in,
                           const int64_t *perm, size_t n, int32_t *user_out, int32_t *anime_out,
