@@ -96,8 +96,11 @@ PROTOTYPES = {
     "anirec_train_stage_ticks": (C.c_int, [_DP, _i32, C.POINTER(C.c_float), C.POINTER(C.c_int32), _vp]),
     "anirec_dist_stepper_create": (C.c_int, [_DP, C.POINTER(_vp)]),
     "anirec_dist_stepper_destroy": (C.c_int, [_vp]),
+    "anirec_dist_step_front": (C.c_int, [_vp, _vp]),
     "anirec_dist_step_mid": (C.c_int, [_vp, _vp]),
     "anirec_dist_step_back": (C.c_int, [_vp, _vp]),
+    "anirec_dist_stepper_begin": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "anirec_dist_stepper_block": (C.c_int, [_vp, _i32]),
     "anirec_rccl_load": (C.c_int, [C.c_char_p]),
     "anirec_rccl_unique_id": (C.c_int, [C.c_char_p]),
     "anirec_dist_comm_create": (C.c_int, [C.c_char_p, _i32, _i32, C.POINTER(_vp)]),

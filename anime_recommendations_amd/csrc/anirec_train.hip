@@ -372,6 +372,7 @@ struct FwdArgs {
 // step really reads, with whatever the previous kernel left in the caches.
 __device__ __forceinline__ void tick(unsigned long long *ticks, int which) {
   if (ticks == nullptr) return;  // kernel-uniform
+  if (blockIdx.x >= ANIREC_ADAM_BLOCKS) return;  // a slot holds ANIREC_ADAM_BLOCKS stamp pairs (workgroup-uniform)
   if (which) {                   // the end stamp covers every wave of the workgroup and its stores
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -676,6 +677,7 @@ struct BwdArgs {
   float *P, *S;
   int32_t *rowmap;
   int32_t *touched;  // lazy dense Adam: [rows], step + 1 for every row the batch touches (or nullptr)
+  int rowmap_lo;     // rows below it get no row-map word (user-sharded lazy mode: nobody would read or clear it)
   int arena_steps;
   unsigned long long *ticks;
 };
@@ -812,7 +814,8 @@ __device__ __forceinline__ void bwd_chunk(const BwdArgs &a, const StepPub &pub, 
   reinterpret_cast<float4 *>(a.P)[pc * kRowVec + l] = acc;
   if (l == 0) {
     a.S[pc] = ssum;
-    if (rec.w > 0 && a.rowmap != nullptr) a.rowmap[(size_t)par * a.rows + rec.x] = ((gc << 10) | (rec.w - 1)) + 1;
+    if (rec.w > 0 && a.rowmap != nullptr && rec.x >= a.rowmap_lo)
+      a.rowmap[(size_t)par * a.rows + rec.x] = ((gc << 10) | (rec.w - 1)) + 1;
     if (rec.w > 0 && a.touched != nullptr) a.touched[rec.x] = pub.step + 1;
   }
 }
@@ -931,6 +934,8 @@ struct AdamArgs {
   size_t hpart_stride;
   float two_l2;
   float *regpart;  // [2][2][ANIREC_ADAM_BLOCKS]
+  float *ring;         // user-sharded lazy mode: the open window's {n, bce mean} per step (else nullptr)
+  const int32_t *w0;   // ... and the first step of that window
   unsigned long long *ticks;
 };
 
@@ -1034,11 +1039,15 @@ __device__ __forceinline__ void block_sq_partials(float sq, float sqa, float *sc
 // the end of step t (one workgroup of 256 threads): reduce the head partials, Adam on (w, b, gamma, beta), moving
 // statistics, History sums, cursors.  The L2 term of the loss is sum(W^2) of the weights step t READ: the partials
 // the launches of step t-1 (or init_reg) left in the other parity.
-// kLazy (the lazy dense Adam): the L2 sums of the step are not known yet — the step's batch count and BCE mean go to
+// kMode 1 (the lazy dense Adam): the L2 sums of the step are not known yet — the step's batch count and BCE mean go to
 // `ring` (slot step - w0) and k_lazy_reduce completes loss / reg_* when the window is flushed.
-template <bool kLazy = false>
+// kMode 2 (user-sharded multi-GPU step with lazy user rows): the anime table is updated densely every step, so its L2
+// sum is here; the user rows' sum is deferred — the step is accounted with the anime term only, its batch count goes
+// to `ring`, and k_lazy_reduce adds the user term of every step of the window at the flush.
+template <int kMode = 0>
 __device__ __forceinline__ void finish_step(const AdamArgs &a, int par, float *scratch, float *ring = nullptr,
                                             int ring_slot = 0) {
+  constexpr bool kLazy = kMode == 1;
   const StepPub pub = a.pub[par];
   const float *hpart = a.hpart + par * a.hpart_stride;
   anirec_state *st = a.state;
@@ -1051,9 +1060,11 @@ __device__ __forceinline__ void finish_step(const AdamArgs &a, int par, float *s
   if (!kLazy) {
 #pragma unroll 2
     for (int i4 = threadIdx.x; i4 < ANIREC_ADAM_BLOCKS / 4; i4 += 256) {
-      const float4 u = ru[i4], v = ra[i4];
-      q[0] += (u.x + u.y) + (u.z + u.w);
+      const float4 v = ra[i4];
       q[1] += (v.x + v.y) + (v.z + v.w);
+      if (kMode == 2) continue;  // (the user partials of a lazy-users step are the flush's business)
+      const float4 u = ru[i4];
+      q[0] += (u.x + u.y) + (u.z + u.w);
     }
   }
   float am[4], av[4];
@@ -1109,13 +1120,14 @@ __device__ __forceinline__ void finish_step(const AdamArgs &a, int par, float *s
       const float reg_u = q[0], reg_a = q[1];
       const float reg = reg_u + reg_a;
       st->reg_sumsq = reg;
-      st->reg_user_sumsq = reg_u;
+      if (kMode != 2) st->reg_user_sumsq = reg_u;
       st->reg_anime_sumsq = reg_a;
       const float loss = (float)(L / n) + pub.l2 * reg;
       st->last_loss = loss;
       st->loss_wsum = o_loss + (double)loss * n;
-      st->reg_user_wsum = o_ru + (double)reg_u * n;
+      if (kMode != 2) st->reg_user_wsum = o_ru + (double)reg_u * n;
       st->reg_anime_wsum = o_ra + (double)reg_a * n;
+      if (kMode == 2) ring[2 * ring_slot + 0] = (float)pub.n_total;
     }
     st->se_sum = o_se + SE;
     st->n_seen = o_n + n;
@@ -1162,7 +1174,12 @@ __device__ __forceinline__ void adam_body(const AdamArgs &a, int bid, int nblock
   float *rp = a.regpart + (size_t)(par * 2) * ANIREC_ADAM_BLOCKS;
   block_sq_partials(sq, sqa, scratch, (a.parts & 1) ? rp + bid : nullptr,
                     (a.parts & 2) ? rp + ANIREC_ADAM_BLOCKS + bid : nullptr);
-  if (bid == 0 && (a.parts & 4)) finish_step<false>(a, par, scratch);
+  if (bid == 0 && (a.parts & 4)) {
+    if (a.ring != nullptr)
+      finish_step<2>(a, par, scratch, a.ring, step - a.w0[0]);
+    else
+      finish_step<0>(a, par, scratch);
+  }
 }
 
 template <bool kNT>
@@ -1206,6 +1223,9 @@ struct LazyArgs {
   int cap, capC, arena_steps;
   float *lzpart, *lzring, *regpart;
   int fuse_nb;  // k_lazy_adam: > 0 = workgroups [fuse_nb, 2 fuse_nb) catch the rows of batch t + 1 up to step t + 1
+  int tables;   // 2: both tables are updated lazily (one GPU); 1: the user rows only (user-sharded multi-GPU step: the
+                // replicated anime rows take their dense update behind the all-reduce every step)
+  int lazy_rows;  // rows [0, lazy_rows) are the lazily updated ones (all rows, or the user rows)
   unsigned long long *ticks;
 };
 
@@ -1422,7 +1442,7 @@ __device__ __forceinline__ int lazy_chunk_row(const LazyArgs &a, int step, int b
   const int T = hw >= a.capC ? 1 : 0;
   const int c = hw - T * a.capC;
   Slot sl = slot_of(a.arena, a.slot_bytes, a.cap, a.capC, step % a.arena_steps);
-  if (hw >= 2 * a.capC || c >= sl.nchunks[T]) return -1;
+  if (hw >= a.tables * a.capC || c >= sl.nchunks[T]) return -1;
   const int4 rec = sl.chunks[T * a.capC + c];
   if (rec.w <= 0) return -1;
   gc = T * a.capC + c;
@@ -1518,7 +1538,7 @@ __global__ __launch_bounds__(256) void k_lazy_adam(LazyArgs a, AdamArgs d) {
       a.z.row_step[row] = step + 1;
     }
   }
-  if (blockIdx.x == 0) finish_step<true>(d, par, scratch, a.lzring, step - w0);
+  if (blockIdx.x == 0 && a.tables == 2) finish_step<1>(d, par, scratch, a.lzring, step - w0);
   tick(a.ticks, 1);
 }
 
@@ -1556,15 +1576,15 @@ __global__ __launch_bounds__(256) void k_lazy_flush(LazyArgs a) {
   Row3 nx;
   nx.w = nx.m = nx.v = make_float4(0.f, 0.f, 0.f, 0.f);
   int ta_n = 0;
-  if (r < a.rows) {
+  if (r < a.lazy_rows) {
     ta_n = a.z.row_step[r];
     load_row(r, nx);
   }
-  for (; r < a.rows; r += nhw) {
+  for (; r < a.lazy_rows; r += nhw) {
     Row3 x = nx;
     const int ta = ta_n;
     const int rn = r + nhw;
-    if (rn < a.rows) {
+    if (rn < a.lazy_rows) {
       ta_n = a.z.row_step[rn];
       load_row(rn, nx);
     }
@@ -1619,8 +1639,10 @@ __global__ __launch_bounds__(256) void k_lazy_flush(LazyArgs a) {
   } else if (threadIdx.x < 2 * kLzWin + 2) {
     const int t = threadIdx.x - 2 * kLzWin;
     const float v = ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
-    a.regpart[(size_t)(0 * 2 + t) * ANIREC_ADAM_BLOCKS + blockIdx.x] = v;
-    a.regpart[(size_t)(1 * 2 + t) * ANIREC_ADAM_BLOCKS + blockIdx.x] = v;
+    if (t < a.tables) {  // (tables == 1: the anime partials belong to the dense launches of every step)
+      a.regpart[(size_t)(0 * 2 + t) * ANIREC_ADAM_BLOCKS + blockIdx.x] = v;
+      a.regpart[(size_t)(1 * 2 + t) * ANIREC_ADAM_BLOCKS + blockIdx.x] = v;
+    }
   }
   tick(a.ticks, 1);
 }
@@ -1658,22 +1680,38 @@ __global__ __launch_bounds__(1024) void k_lazy_reduce(LazyArgs a) {
     anirec_state *st = a.state;
     double o_loss = st->loss_wsum, o_ru = st->reg_user_wsum, o_ra = st->reg_anime_wsum;
     float loss = 0.f, ru = 0.f, ra = 0.f;
-    for (int j = 0; j < nj && j < kLzWin; ++j) {
-      const double n = (double)a.lzring[2 * j + 0];
-      ru = reg[j][0];
-      ra = reg[j][1];
-      loss = a.lzring[2 * j + 1] + a.l2 * (ru + ra);
-      o_loss += (double)loss * n;
-      o_ru += (double)ru * n;
-      o_ra += (double)ra * n;
+    if (a.tables == 1) {
+      // user rows only: every step of the window was accounted with its anime term when it finished; add the user
+      // term (this rank's rows) of each
+      for (int j = 0; j < nj && j < kLzWin; ++j) {
+        const double n = (double)a.lzring[2 * j + 0];
+        ru = reg[j][0];
+        o_loss += (double)(a.l2 * ru) * n;
+        o_ru += (double)ru * n;
+      }
+      st->loss_wsum = o_loss;
+      st->reg_user_wsum = o_ru;
+      st->last_loss = st->last_loss + a.l2 * ru;
+      st->reg_user_sumsq = ru;
+      st->reg_sumsq = ru + st->reg_anime_sumsq;
+    } else {
+      for (int j = 0; j < nj && j < kLzWin; ++j) {
+        const double n = (double)a.lzring[2 * j + 0];
+        ru = reg[j][0];
+        ra = reg[j][1];
+        loss = a.lzring[2 * j + 1] + a.l2 * (ru + ra);
+        o_loss += (double)loss * n;
+        o_ru += (double)ru * n;
+        o_ra += (double)ra * n;
+      }
+      st->loss_wsum = o_loss;
+      st->reg_user_wsum = o_ru;
+      st->reg_anime_wsum = o_ra;
+      st->last_loss = loss;
+      st->reg_sumsq = ru + ra;
+      st->reg_user_sumsq = ru;
+      st->reg_anime_sumsq = ra;
     }
-    st->loss_wsum = o_loss;
-    st->reg_user_wsum = o_ru;
-    st->reg_anime_wsum = o_ra;
-    st->last_loss = loss;
-    st->reg_sumsq = ru + ra;
-    st->reg_user_sumsq = ru;
-    st->reg_anime_sumsq = ra;
     a.w0[0] = upto;
   }
   tick(a.ticks, 1);
@@ -1862,6 +1900,16 @@ static inline int table_rows(const anirec_train_desc *d) { return d->n_user_rows
 // first table row whose gradient travels through the dense buffer
 static inline int dense_lo_of(const anirec_train_desc *d) { return d->dense_mode == 2 ? 0 : d->n_user_rows; }
 
+// ---- which update the descriptor asks for ----
+static inline bool lazy_on(const anirec_train_desc *d) {
+  return d->lazy != 0 && d->lazy_state != nullptr && d->dense_mode == 0 && d->n_seg == 1;
+}
+// the user-sharded multi-GPU step with lazily updated user rows (the replicated anime rows stay dense: their
+// gradient is summed over the ranks every step and most of them are touched by the global batch anyway)
+static inline bool lazy_users(const anirec_train_desc *d) {
+  return d->lazy != 0 && d->lazy_state != nullptr && d->dense_mode == 1;
+}
+
 static int check_desc(const anirec_train_desc *d) {
   if (!d || !d->W || !d->M || !d->V || !d->rowmap || !d->state || !d->workspace || !d->packets)
     return ANIREC_EINVAL;
@@ -2013,6 +2061,7 @@ static BwdArgs bwd_args(const anirec_train_desc *d, const TrainWs &w) {
   a.S = w.S;
   a.rowmap = d->rowmap;
   a.touched = nullptr;
+  a.rowmap_lo = 0;
   a.arena_steps = w.arena_steps;
   a.ticks = ticks_of(w, 2);
   return a;
@@ -2021,7 +2070,10 @@ static BwdArgs bwd_args(const anirec_train_desc *d, const TrainWs &w) {
 static int launch_bwd_only(const anirec_train_desc *d, const TrainWs &w, hipStream_t s, bool lazy = false) {
   BwdArgs a = bwd_args(d, w);
   if (lazy) {  // the lazy update walks the chunk table itself: no row map to fill (or to clear), but a mark per row
-    a.rowmap = nullptr;
+    if (d->dense_mode == 1)
+      a.rowmap_lo = d->n_user_rows;  // (user-sharded step: the densify pass still wants the anime rows' words)
+    else
+      a.rowmap = nullptr;
     a.touched = lazy_carve(d->lazy_state, table_rows(d)).mark;
   }
   hipLaunchKernelGGL(k_bwd, dim3((2 * w.capC + 7) / 8), dim3(256), 0, s, a);
@@ -2070,6 +2122,8 @@ static AdamArgs adam_args(const anirec_train_desc *d, const TrainWs &w) {
   a.hpart_stride = w.hpart_stride;
   a.two_l2 = 2.0f * d->l2;
   a.regpart = w.regpart;
+  a.ring = nullptr;
+  a.w0 = nullptr;
   a.ticks = ticks_of(w, 3);
   return a;
 }
@@ -2094,6 +2148,10 @@ static int launch_adam_full(const anirec_train_desc *d, const TrainWs &w, hipStr
   } else if (which == 2) {
     a.row_lo = d->n_user_rows;
     a.parts = 2 | 4;
+    if (lazy_users(d)) {  // the step is accounted with its anime L2 term only; the flush adds the user rows' (finish_step<2>)
+      a.ring = w.lzring;
+      a.w0 = w.sel + 1;
+    }
   }
   if (stream_nt(d))
     hipLaunchKernelGGL((k_adam<true>), dim3(adam_grid(d)), dim3(256), 0, s, a);
@@ -2108,10 +2166,6 @@ static int launch_adam(const anirec_train_desc *d, const TrainWs &w, hipStream_t
 }
 
 // ---- lazy dense Adam: host side ----
-static inline bool lazy_on(const anirec_train_desc *d) {
-  return d->lazy != 0 && d->lazy_state != nullptr && d->dense_mode == 0 && d->n_seg == 1;
-}
-
 static LazyArgs lazy_args(const anirec_train_desc *d, const TrainWs &w, int ticks_slot) {
   LazyArgs a;
   a.W = d->W;
@@ -2135,8 +2189,23 @@ static LazyArgs lazy_args(const anirec_train_desc *d, const TrainWs &w, int tick
   a.lzring = w.lzring;
   a.regpart = w.regpart;
   a.fuse_nb = 0;
+  a.tables = lazy_users(d) ? 1 : 2;
+  a.lazy_rows = lazy_users(d) ? d->n_user_rows : table_rows(d);
   a.ticks = ticks_of(w, ticks_slot);
   return a;
+}
+
+// grid of the lazy kernels that walk the chunk table (a half-wave per chunk slot of the lazily updated tables)
+static inline int lazy_chunk_grid(const anirec_train_desc *d, const TrainWs &w) {
+  return ((lazy_users(d) ? 1 : 2) * w.capC + 7) / 8;
+}
+// grid of the flush: a function of the lazily updated row count only (the same partial slots every window)
+static inline int flush_grid(const anirec_train_desc *d) {
+  const long long rows = lazy_users(d) ? d->n_user_rows : table_rows(d);
+  long long b = (rows + 15) / 16;
+  if (b < 64) b = 64;
+  if (b > ANIREC_ADAM_BLOCKS) b = ANIREC_ADAM_BLOCKS;
+  return (int)b;
 }
 
 // every row is current as of `first_step` (each anirec_trainer_run call ends flushed): open a window there
@@ -2151,30 +2220,39 @@ static int lazy_begin(const anirec_train_desc *d, const TrainWs &w, int first_st
 // catchup_first: the rows of this step's batch are not known to be current (first step of a run or of a prepared
 // block): a stand-alone catch-up launch.  fuse_next: the NEXT step's batch is already in the prep arena, so the sparse
 // launch also catches its rows up (second half of its grid) and the next step needs no catch-up launch.
-static int lazy_step(const anirec_train_desc *d, const TrainWs &w, hipStream_t s, bool catchup_first, bool fuse_next) {
-  const int grid = (2 * w.capC + 7) / 8;
-  int e;
-  if (catchup_first) {
-    hipLaunchKernelGGL(k_lazy_catchup, dim3(grid), dim3(256), 0, s, lazy_args(d, w, 4));
-    if ((e = ticks_collect(w, 4, s))) return e;
-  }
-  if ((e = launch_fwd(d, w, s))) return e;
-  if ((e = launch_head(d, w, s))) return e;
-  if ((e = launch_bwd_only(d, w, s, true))) return e;
+static int launch_lazy_catchup(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
+  hipLaunchKernelGGL(k_lazy_catchup, dim3(lazy_chunk_grid(d, w)), dim3(256), 0, s, lazy_args(d, w, 4));
+  if (int e = ticks_collect(w, 4, s)) return e;
+  return (int)hipGetLastError();
+}
+
+// the sparse step of the batch bwd has just processed (+ the catch-up of the next batch's rows when its chunk table
+// is already in the arena)
+static int launch_lazy_adam(const anirec_train_desc *d, const TrainWs &w, hipStream_t s, bool fuse_next) {
+  const int grid = lazy_chunk_grid(d, w);
   AdamArgs aa = adam_args(d, w);
   aa.ticks = nullptr;
   LazyArgs la = lazy_args(d, w, 5);
   la.fuse_nb = fuse_next ? grid : 0;
   hipLaunchKernelGGL(k_lazy_adam, dim3(fuse_next ? 2 * grid : grid), dim3(256), 0, s, la, aa);
-  if ((e = ticks_collect(w, 5, s))) return e;
+  if (int e = ticks_collect(w, 5, s)) return e;
   return (int)hipGetLastError();
+}
+
+static int lazy_step(const anirec_train_desc *d, const TrainWs &w, hipStream_t s, bool catchup_first, bool fuse_next) {
+  int e;
+  if (catchup_first && (e = launch_lazy_catchup(d, w, s))) return e;
+  if ((e = launch_fwd(d, w, s))) return e;
+  if ((e = launch_head(d, w, s))) return e;
+  if ((e = launch_bwd_only(d, w, s, true))) return e;
+  return launch_lazy_adam(d, w, s, fuse_next);
 }
 
 static int lazy_flush(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
   if (stream_nt(d))
-    hipLaunchKernelGGL((k_lazy_flush<true>), dim3(adam_grid(d)), dim3(256), 0, s, lazy_args(d, w, 6));
+    hipLaunchKernelGGL((k_lazy_flush<true>), dim3(flush_grid(d)), dim3(256), 0, s, lazy_args(d, w, 6));
   else
-    hipLaunchKernelGGL((k_lazy_flush<false>), dim3(adam_grid(d)), dim3(256), 0, s, lazy_args(d, w, 6));
+    hipLaunchKernelGGL((k_lazy_flush<false>), dim3(flush_grid(d)), dim3(256), 0, s, lazy_args(d, w, 6));
   if (int te = ticks_collect(w, 6, s)) return te;
   hipLaunchKernelGGL(k_lazy_reduce, dim3(1), dim3(1024), 0, s, lazy_args(d, w, 7));
   if (int te = ticks_collect(w, 7, s)) return te;
@@ -2320,6 +2398,10 @@ struct anirec_dist_stepper {
   hipEvent_t fork, join;
   hipGraphExec_t exec;  // anirec_dist_run(use_graph): a captured block of steps, collectives included
   int graph_steps;
+  // lazy user rows (desc.lazy, dense_mode 1): where the step-by-step callers are in their run / prepared block
+  int run_left;  // steps of the current run still to come (anirec_dist_stepper_begin)
+  int blk_len, blk_pos;  // the prepared block the next step belongs to (anirec_dist_stepper_block)
+  int lz_open;   // steps taken since the last flush
 };
 
 int anirec_dist_stepper_create(const anirec_train_desc *d, anirec_dist_stepper **out) {
@@ -2335,6 +2417,7 @@ int anirec_dist_stepper_create(const anirec_train_desc *d, anirec_dist_stepper *
   h->fork = h->join = nullptr;
   h->exec = nullptr;
   h->graph_steps = 0;
+  h->run_left = h->blk_len = h->blk_pos = h->lz_open = 0;
   if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&h->fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->join, hipEventDisableTiming) != hipSuccess) {
@@ -2355,33 +2438,91 @@ int anirec_dist_stepper_destroy(anirec_dist_stepper *h) {
   return ANIREC_OK;
 }
 
-// after the all-gather of the head packets: head, bwd, and the densify pass that feeds the gradient collective.
-// User-sharded mode: the dense Adam stream over this rank's user rows needs nothing from the collective, so it
-// is forked onto the stepper's side stream right behind bwd and runs beside densify + all-reduce.
-int anirec_dist_step_mid(anirec_dist_stepper *h, void *stream) {
-  if (!h) return ANIREC_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
+// ---- the three parts of a multi-GPU step (the collectives go between them) ----------------------------------
+// front: [lazy user rows: the catch-up of this batch's rows when no earlier step of the block has done it] + fwd
+static int dist_front(anirec_dist_stepper *h, hipStream_t s, bool catchup_first) {
+  int e;
+  if (lazy_users(&h->d) && catchup_first && (e = launch_lazy_catchup(&h->d, h->ws, s))) return e;
+  return launch_fwd(&h->d, h->ws, s);
+}
+
+// mid — after the all-gather of the head packets: head, bwd, and the densify pass that feeds the gradient
+// collective.  User-sharded mode: the update of this rank's user rows needs nothing from the collective, so it is
+// forked onto the stepper's side stream right behind bwd and runs beside densify + all-reduce: the dense Adam stream
+// over the user rows, or — lazy user rows — the sparse step of the rows the batch touched (+ the catch-up of the next
+// batch's rows when `fuse_next`: its chunk table is in the arena).
+static int dist_mid(anirec_dist_stepper *h, hipStream_t s, bool fuse_next) {
+  const bool lz = lazy_users(&h->d);
   int e;
   if ((e = launch_head(&h->d, h->ws, s))) return e;
-  if ((e = launch_bwd_only(&h->d, h->ws, s))) return e;
+  if ((e = launch_bwd_only(&h->d, h->ws, s, lz))) return e;
   if (h->d.dense_mode == 1) {
     ANIREC_HIP_CHECK(hipEventRecord(h->fork, s));
     ANIREC_HIP_CHECK(hipStreamWaitEvent(h->side, h->fork, 0));
-    if ((e = launch_adam_full(&h->d, h->ws, h->side, 1))) return e;
+    if ((e = lz ? launch_lazy_adam(&h->d, h->ws, h->side, fuse_next) : launch_adam_full(&h->d, h->ws, h->side, 1)))
+      return e;
     ANIREC_HIP_CHECK(hipEventRecord(h->join, h->side));
   }
   return launch_densify(&h->d, h->ws, s);
 }
 
-// after the gradient collective: the rows that needed it + the step finish
-int anirec_dist_step_back(anirec_dist_stepper *h, void *stream) {
-  if (!h) return ANIREC_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
+// back — after the gradient collective: the rows that needed it + the step finish [+ lazy user rows: the flush of
+// the window when `flush_after`]
+static int dist_back(anirec_dist_stepper *h, hipStream_t s, bool flush_after) {
+  int e;
   if (h->d.dense_mode == 1) {
     ANIREC_HIP_CHECK(hipStreamWaitEvent(s, h->join, 0));
-    return launch_adam_full(&h->d, h->ws, s, 2);
+    e = launch_adam_full(&h->d, h->ws, s, 2);
+  } else {
+    e = launch_adam_full(&h->d, h->ws, s, 0);
   }
-  return launch_adam_full(&h->d, h->ws, s, 0);
+  if (!e && flush_after && lazy_users(&h->d)) e = lazy_flush(&h->d, h->ws, s);
+  return e;
+}
+
+// Callers that drive the step themselves (three C calls + their own collectives per step) say where they are:
+// begin(first_step, n_steps) once per run — the tables are current there, a lazy window opens — and block(n) after
+// every anirec_train_prep of n steps.  With lazy user rows both are REQUIRED (ANIREC_EINVAL from the step calls
+// otherwise: a run that is never told where it ends would leave the tables behind); without, they are no-ops.
+int anirec_dist_stepper_begin(anirec_dist_stepper *h, int32_t first_step, int32_t n_steps, void *stream) {
+  if (!h || first_step < 0 || n_steps < 0 || first_step + n_steps > h->d.n_steps) return ANIREC_EINVAL;
+  h->run_left = n_steps;
+  h->blk_len = h->blk_pos = h->lz_open = 0;
+  if (lazy_users(&h->d) && n_steps > 0) return lazy_begin(&h->d, h->ws, first_step, (hipStream_t)stream);
+  return ANIREC_OK;
+}
+
+int anirec_dist_stepper_block(anirec_dist_stepper *h, int32_t n_steps) {
+  if (!h || n_steps < 0 || n_steps > h->d.arena_steps) return ANIREC_EINVAL;
+  h->blk_len = n_steps;
+  h->blk_pos = 0;
+  return ANIREC_OK;
+}
+
+int anirec_dist_step_front(anirec_dist_stepper *h, void *stream) {
+  if (!h) return ANIREC_EINVAL;
+  if (lazy_users(&h->d) && (h->run_left <= 0 || h->blk_pos >= h->blk_len)) return ANIREC_EINVAL;
+  return dist_front(h, (hipStream_t)stream, h->blk_pos == 0);
+}
+
+int anirec_dist_step_mid(anirec_dist_stepper *h, void *stream) {
+  if (!h) return ANIREC_EINVAL;
+  if (lazy_users(&h->d) && (h->run_left <= 0 || h->blk_pos >= h->blk_len)) return ANIREC_EINVAL;
+  return dist_mid(h, (hipStream_t)stream, h->blk_pos + 1 < h->blk_len);
+}
+
+int anirec_dist_step_back(anirec_dist_stepper *h, void *stream) {
+  if (!h) return ANIREC_EINVAL;
+  bool flush = false;
+  if (lazy_users(&h->d)) {
+    if (h->run_left <= 0 || h->blk_pos >= h->blk_len) return ANIREC_EINVAL;
+    flush = ++h->lz_open == kLzWin || h->run_left == 1;
+    if (flush) h->lz_open = 0;
+  }
+  const int e = dist_back(h, (hipStream_t)stream, flush);
+  if (h->run_left > 0) --h->run_left;
+  if (h->blk_pos < h->blk_len) ++h->blk_pos;
+  return e;
 }
 
 // ---- multi-GPU: the whole loop in the library, RCCL called from here -----------------------------------------
@@ -2486,14 +2627,15 @@ static inline bool row_sharded(const anirec_train_desc *d) {
   return d->dense_mode == 2 && (d->adam_row_lo | d->adam_row_hi) != 0;
 }
 
-static int dist_one_step(anirec_dist_stepper *h, anirec_dist_comm *c, hipStream_t s) {
+static int dist_one_step(anirec_dist_stepper *h, anirec_dist_comm *c, hipStream_t s, bool catchup_first, bool fuse_next,
+                         bool flush_after) {
   const anirec_train_desc *d = &h->d;
   int e;
-  if ((e = launch_fwd(d, h->ws, s))) return e;
+  if ((e = dist_front(h, s, catchup_first))) return e;
   // BatchNorm sees the global batch: every rank's (c, t, count, mean, M2) packet, gathered in place
   const size_t pf = anirec_packet_floats(d->max_batch);
   ANIREC_RCCL_CHECK(g_rccl.AllGather(d->packets + pf * (size_t)c->rank, d->packets, pf, ncclFloat, c->comm, s));
-  if ((e = anirec_dist_step_mid(h, s))) return e;
+  if ((e = dist_mid(h, s, fuse_next))) return e;
   float *g = d->dense_grad;
   const size_t nd = (size_t)d->dense_rows;
   if (row_sharded(d)) {
@@ -2507,7 +2649,7 @@ static int dist_one_step(anirec_dist_stepper *h, anirec_dist_comm *c, hipStream_
   } else {
     ANIREC_RCCL_CHECK(g_rccl.AllReduce(g, g, nd * (kDim + 1), ncclFloat, ncclSum, c->comm, s));
   }
-  if ((e = anirec_dist_step_back(h, s))) return e;
+  if ((e = dist_back(h, s, flush_after))) return e;
   if (row_sharded(d)) {  // every rank updated its row shard: collect the updated rows of W (padded to whole shards)
     const size_t sr = nd / (size_t)c->world;
     ANIREC_RCCL_CHECK(g_rccl.AllGather(d->W + (size_t)c->rank * sr * kDim, d->W, sr * kDim, ncclFloat, c->comm, s));
@@ -2536,7 +2678,10 @@ int anirec_dist_run(anirec_dist_stepper *h, anirec_dist_comm *c, int32_t first_s
     int e = ANIREC_ECAPTURE;
     if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
       e = launch_prep(&h->d, h->ws, G, G, true, s);  // steps cursor+G .. cursor+2G
-      for (int i = 0; i < G && !e; ++i) e = dist_one_step(h, c, s);
+      // lazy user rows: as in the one-GPU capture — only the block's first step needs a catch-up launch of its own,
+      // a flush every kLzWin steps and at the end of the block (a replay leaves the tables up to date)
+      for (int i = 0; i < G && !e; ++i)
+        e = dist_one_step(h, c, s, i == 0, i + 1 < G, (i + 1) % kLzWin == 0 || i + 1 == G);
       if (hipStreamEndCapture(s, &g) != hipSuccess || !g) e = e ? e : ANIREC_ECAPTURE;
     }
     if (!e && hipGraphInstantiate(&h->exec, g, nullptr, nullptr, 0) != hipSuccess) {
@@ -2552,6 +2697,10 @@ int anirec_dist_run(anirec_dist_stepper *h, anirec_dist_comm *c, int32_t first_s
       h->graph_steps = G;
     }
   }
+  if (lazy_users(&h->d) && n_steps > 0) {  // every row is current at first_step: a lazy window opens there
+    const int e = lazy_begin(&h->d, h->ws, first_step, s);
+    if (e) return e;
+  }
   if (graph) {
     int e = launch_prep(&h->d, h->ws, first_step, G, false, s);  // the first block; later ones by the graph
     if (e) return e;
@@ -2560,6 +2709,7 @@ int anirec_dist_run(anirec_dist_stepper *h, anirec_dist_comm *c, int32_t first_s
       done += G;
     }
   }
+  int open = 0;  // lazy user rows: steps since the last flush (eager part)
   while (done < n_steps) {
     int blk = n_steps - done;
     if (!(graph && done > 0)) {  // no replay before: prepare arena-sized blocks from the host
@@ -2568,7 +2718,9 @@ int anirec_dist_run(anirec_dist_stepper *h, anirec_dist_comm *c, int32_t first_s
       if (e) return e;
     }
     for (int i = 0; i < blk; ++i) {
-      int e = dist_one_step(h, c, s);
+      const bool flush = ++open == kLzWin || (i + 1 == blk && done + blk >= n_steps);
+      if (flush) open = 0;
+      int e = dist_one_step(h, c, s, i == 0, i + 1 < blk, flush);
       if (e) return e;
     }
     done += blk;

@@ -107,7 +107,7 @@ class DistTrainEngine:
     """TrainEngine facade for G ranks (same interface as engine.TrainEngine for trainer.fit)."""
 
     def __init__(self, n_users, n_anime, batch_per_rank, l2=1e-4, arena_steps=64, device="cuda:0",
-                 engine_factory=None, mode=None):
+                 engine_factory=None, mode=None, lazy=None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
@@ -127,7 +127,9 @@ class DistTrainEngine:
         if self.mode == "sharded":
             self.n_local = local_user_rows(self.n_users, self.rank, self.world)
             max_batch = min(_lib.MAX_BATCH, batch_slack(self.batch_per_rank))
-            kw = dict(dense_mode=1 if loop else 0)
+            # lazy: the lazy dense Adam — of the whole step on one rank without the loop, of this rank's user rows in
+            # the user-sharded loop (None: the engine decides from the shard size; ANIREC_LAZY_ADAM overrides)
+            kw = dict(dense_mode=1 if loop else 0, lazy=lazy)
         else:
             self.n_local = self.n_users
             max_batch = self.batch_per_rank
@@ -350,9 +352,11 @@ class DistTrainEngine:
             return n_steps
         done = 0
         with torch.cuda.stream(e.stream) if self.device.type == "cuda" else _null_ctx():
+            e.stepper_begin(first_step, n_steps)       # (lazy user rows: a window opens here, the last step flushes)
             while done < n_steps:
                 blk = min(e.arena_steps, n_steps - done)
                 e.prep(first_step + done, blk)
+                e.stepper_block(blk)
                 for _ in range(blk):
                     self.step()
                 done += blk

@@ -162,9 +162,11 @@ def _train_leg(mode, data, tables, n_users, n_anime, B, K, W, inst, rank, world,
     done = 0
     if eng.loop:
         with torch.cuda.stream(e.stream):
+            e.stepper_begin(W + K, inst)
             while done < inst:
                 blk = min(e.arena_steps, inst - done)
                 e.prep(W + K + done, blk)
+                e.stepper_block(blk)
                 for _ in range(blk):
                     timed("front", e.step_front)
                     timed("gather", eng._all_gather_packets)

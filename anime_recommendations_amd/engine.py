@@ -34,10 +34,13 @@ class TrainEngine:
         tables (every gradient through ``dense_grad``).  row_pad: the tables and the dense buffer are
         allocated with their row count rounded up to a multiple of it (equal reduce-scatter / all-gather
         shards).  adam_rows: (lo, hi) row shard this rank's Adam updates in mode 2, None = all.
-        lazy: the lazy dense Adam of ``run`` (include/anirec.h: rows a batch does not touch take their L2-only steps
-        later, several at a time; tables and Adam state bit-identical to the dense update).  None = automatic: one
-        GPU and tables of at least 8 batches' worth of rows (below that most rows are touched every few steps and
-        the plain dense stream is faster); ANIREC_LAZY_ADAM=0/1 overrides."""
+        lazy: the lazy dense Adam (include/anirec.h: rows a batch does not touch take their L2-only steps later,
+        several at a time; tables and Adam state bit-identical to the dense update) — of ``run`` on one GPU (both
+        tables) and of the user-sharded multi-GPU step (dense_mode 1: this rank's user rows; the replicated anime
+        rows keep their dense update behind the all-reduce).  None = automatic: tables of at least 8 batches' worth of
+        rows on one GPU, user shards of at least 4 in mode 1 (below that most rows are touched every few steps and
+        the plain dense stream is faster); ANIREC_LAZY_ADAM=0/1 overrides.  Never in dense_mode 2: that step is
+        bound by its 188 MB collectives, not by the Adam stream."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.AnirecError("no GPU: the anime_recommendations_amd hot path needs an MI355X")
@@ -73,8 +76,9 @@ class TrainEngine:
         if lazy is None:
             import os
             env = os.environ.get("ANIREC_LAZY_ADAM")
-            lazy = (env != "0") and (env == "1" or self.rows >= 8 * self.max_batch)
-        self.lazy = bool(lazy) and self.dense_mode == 0 and self.n_seg == 1
+            big = (self.rows >= 8 * self.max_batch) if self.dense_mode == 0 else (self.n_user_rows >= 4 * self.max_batch)
+            lazy = (env != "0") and (env == "1" or big)
+        self.lazy = bool(lazy) and ((self.dense_mode == 0 and self.n_seg == 1) or self.dense_mode == 1)
         self.lazy_state = (_dev_bytes(int(self.lib.anirec_train_lazy_bytes(self.rows)), dev) if self.lazy else None)
         self._stepper = None
         self.stream = torch.cuda.Stream(device=dev)
@@ -277,8 +281,18 @@ class TrainEngine:
             self._stepper = h
         return self._stepper
 
+    def stepper_begin(self, first_step, n_steps):
+        """A run of n_steps steps driven through step_front / step_mid / step_back starts at first_step (the tables
+        are current there); required with lazy user rows, a no-op otherwise."""
+        _lib.check(self.lib.anirec_dist_stepper_begin(self._get_stepper(), int(first_step), int(n_steps), self._sp()),
+                   "anirec_dist_stepper_begin")
+
+    def stepper_block(self, n_steps):
+        """The next n_steps steps have just been prepared (``prep``)."""
+        _lib.check(self.lib.anirec_dist_stepper_block(self._get_stepper(), int(n_steps)), "anirec_dist_stepper_block")
+
     def step_front(self):
-        self.fwd()
+        _lib.check(self.lib.anirec_dist_step_front(self._get_stepper(), self._sp()), "anirec_dist_step_front")
 
     def step_mid(self):
         _lib.check(self.lib.anirec_dist_step_mid(self._get_stepper(), self._sp()), "anirec_dist_step_mid")

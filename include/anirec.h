@@ -115,8 +115,9 @@ typedef struct anirec_train_desc {
   float l2;             /* lambda of embeddings_regularizer L2 (neural_network.py:73) */
   int32_t adam_row_lo;  /* mode 2: adam updates table rows [adam_row_lo, adam_row_hi) only (the caller */
   int32_t adam_row_hi;  /* all-gathers W afterwards); 0,0 = every row */
-  int32_t lazy;         /* != 0 (one GPU only, `lazy_state` set): anirec_trainer_run defers the dense update of the rows
-                           a batch does not touch — see anirec_trainer_run */
+  int32_t lazy;         /* != 0 (`lazy_state` set): the dense update of the rows a batch does not touch is deferred —
+                           dense_mode 0: both tables, inside anirec_trainer_run; dense_mode 1: the rank's user rows,
+                           inside anirec_dist_run / the stepper calls (LAZY USER ROWS); ignored in dense_mode 2 */
   /* tables: rows [0,n_user_rows) users, then n_anime_rows anime; [rows][128] fp32.
    * W = embeddings, M/V = Adam first/second moments. */
   float *W, *M, *V;
@@ -190,8 +191,21 @@ int anirec_train_adam_part(const anirec_train_desc *d, int32_t which, void *stre
 typedef struct anirec_dist_stepper anirec_dist_stepper;
 int anirec_dist_stepper_create(const anirec_train_desc *d, anirec_dist_stepper **out_host);
 int anirec_dist_stepper_destroy(anirec_dist_stepper *h);
+/* anirec_dist_step_front = anirec_train_fwd, preceded — lazy user rows, below — by the catch-up of the batch's rows
+ * when the step is the first of its prepared block. */
+int anirec_dist_step_front(anirec_dist_stepper *h, void *stream);
 int anirec_dist_step_mid(anirec_dist_stepper *h, void *stream);
 int anirec_dist_step_back(anirec_dist_stepper *h, void *stream);
+/* LAZY USER ROWS (desc->lazy != 0 with dense_mode 1; see LAZY DENSE ADAM below).  In the user-sharded step the dense
+ * Adam stream over the rank's user rows becomes: sparse step of the rows the batch touched (forked beside densify +
+ * all-reduce, with the catch-up of the next batch's rows), a flush of the user rows every ANIREC_LAZY_WINDOW steps and
+ * at the end of a run.  The replicated anime rows keep their dense update behind the all-reduce.  Tables, Adam moments
+ * and scalar state stay bit-identical to the dense step; reg_user_wsum / loss_wsum receive the user rows' L2 term at
+ * the flush.  A caller that drives the steps itself must tell the stepper where it is: _begin(first_step, n_steps)
+ * once per run (the tables are current there; stream-ordered) and _block(n) after every anirec_train_prep of n steps;
+ * without them the step calls of a lazy descriptor return ANIREC_EINVAL.  anirec_dist_run does both itself. */
+int anirec_dist_stepper_begin(anirec_dist_stepper *h, int32_t first_step, int32_t n_steps, void *stream);
+int anirec_dist_stepper_block(anirec_dist_stepper *h, int32_t n_steps);
 
 /* The same loop inside the library, the collectives issued to RCCL from C on the engine's stream (one call per
  * block of steps instead of three C calls and two torch.distributed calls per step).  Replaces the reference's only

@@ -26,7 +26,7 @@ class NumpyStageEngine:
     layouts and the same three step halves as libanirec, arithmetic from the oracle's formulas."""
 
     def __init__(self, n_user_rows, n_anime_rows, max_batch, l2=1e-4, arena_steps=64, device="cpu",
-                 n_seg=1, my_seg=0, dense_mode=1, row_pad=1, adam_rows=None):
+                 n_seg=1, my_seg=0, dense_mode=1, row_pad=1, adam_rows=None, lazy=None):
         self.device = torch.device("cpu")
         self.n_u, self.n_a, self.cap = n_user_rows, n_anime_rows, max_batch
         self.max_batch = max_batch
@@ -80,7 +80,20 @@ class NumpyStageEngine:
             self.acc[k] = 0.0
 
     def prep(self, first, n):
-        pass
+        self._prepared = (first, n)
+
+    # the stepper protocol of libanirec (anirec_dist_stepper_begin / _block): the step halves of a lazy descriptor
+    # refuse to run outside a declared run and prepared block — the stand-in holds the Python loop to the same rules
+    def stepper_begin(self, first_step, n_steps):
+        assert first_step == self.step and 0 <= n_steps <= self.n_steps - first_step
+        self._run_left, self._blk_len, self._blk_pos = n_steps, 0, 0
+
+    def stepper_block(self, n_steps):
+        assert self._prepared == (self.step, n_steps) and 0 < n_steps <= min(self.arena_steps, self._run_left)
+        self._blk_len, self._blk_pos = n_steps, 0
+
+    def _in_block(self):
+        assert self._run_left > 0 and self._blk_pos < self._blk_len, "step outside a declared run / prepared block"
 
     def synchronize(self):
         pass
@@ -91,6 +104,7 @@ class NumpyStageEngine:
         return lu[s:s + c], la[s:s + c], lt[s:s + c], alphas[self.step]
 
     def step_front(self):
+        self._in_block()
         lu, la, lt, _ = self._batch()
         u, a = self.Uw[lu], self.Aw[la]
         self.su, self.sa = np.sum(u * u, 1, dtype=f32), np.sum(a * a, 1, dtype=f32)
@@ -138,6 +152,7 @@ class NumpyStageEngine:
     def step_mid(self):
         """head + bwd + densify: sparse part of the gradient, rows >= dense_lo into the dense buffer
         ([dense_rows][128] sums of coef * other row, then [dense_rows] self-coefficient sums)."""
+        self._in_block()
         self._head()
         lu, la, lt, _ = self._batch()
         ru, ra = orc._inv_norm(self.su, f32), orc._inv_norm(self.sa, f32)
@@ -158,6 +173,9 @@ class NumpyStageEngine:
         G[nd * 128:][: self.rows - lo] = s[lo:]
 
     def step_back(self):
+        self._in_block()
+        self._run_left -= 1
+        self._blk_pos += 1
         _, _, _, alpha = self._batch()
         lo_r, hi_r = self.adam_rows if (self.adam_rows[0] | self.adam_rows[1]) else (0, self.rows)
         W = self.Wn[: self.rows]

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 
 def _problem():
     rng = np.random.default_rng(21)
-    n_u, n_a, n = 3001, 700, 5 * 2000 - 333
+    n_u, n_a, n = 3001, 700, 11 * 2000 - 333       # 11 global batches: a full lazy window of 8, then a ragged one
     U = rng.uniform(-0.05, 0.05, (n_u, 128)).astype(np.float32)
     A = rng.uniform(-0.05, 0.05, (n_a, 128)).astype(np.float32)
     ui = rng.integers(0, n_u, n)
@@ -30,7 +30,7 @@ def _problem():
     return U, A, ui, ai, t, rng.permutation(n)
 
 
-def _worker(rank, world, port, out_dir, mode="sharded", backend="gloo"):
+def _worker(rank, world, port, out_dir, mode="sharded", backend="gloo", lazy=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dev = torch.device("cuda:%d" % (rank if backend == "nccl" else 0))
     if backend == "nccl":
@@ -42,7 +42,8 @@ def _worker(rank, world, port, out_dir, mode="sharded", backend="gloo"):
         from anime_recommendations_amd import schedule
         from anime_recommendations_amd.dist import DistTrainEngine
         U, A, ui, ai, t, perm = _problem()
-        eng = DistTrainEngine(U.shape[0], A.shape[0], 1000, l2=1e-4, arena_steps=4, device=dev, mode=mode)
+        eng = DistTrainEngine(U.shape[0], A.shape[0], 1000, l2=1e-4, arena_steps=4, device=dev, mode=mode, lazy=lazy)
+        assert eng.eng.lazy == bool(lazy)
         eng.set_head(w=1.2)
         eng.set_weights(U, A)
         tu, ta, tt, tp = (torch.from_numpy(np.asarray(x)).to(dev) for x in (ui, ai, t, perm))
@@ -108,16 +109,27 @@ def _check_against_oracle(tmp_path):
     assert abs(float(d["vl"]) - float(ev["val_loss"])) < 5e-6 and abs(float(d["vm"]) - float(ev["val_mse"])) < 1e-6
 
 
-@pytest.mark.parametrize("mode", ["sharded", "replicated", "replicated_rs"])
+# "sharded-lazy": the user-sharded step with lazily updated user rows (sparse step + catch-up beside the all-reduce,
+# a flush every 8 steps and at the end of the run) — what bench.py --gpus N runs at the S109M shape
+_MODES = ["sharded", "sharded-lazy", "replicated", "replicated_rs"]
+
+
+def _mode_args(mode):
+    return ("sharded", True) if mode == "sharded-lazy" else (mode, False)
+
+
+@pytest.mark.parametrize("mode", _MODES)
 def test_two_ranks_on_one_gpu_match_oracle_on_global_batches(tmp_path, mode):
-    mp.spawn(_worker, args=(2, _port(), str(tmp_path), mode), nprocs=2, join=True)
+    m, lazy = _mode_args(mode)
+    mp.spawn(_worker, args=(2, _port(), str(tmp_path), m, "gloo", lazy), nprocs=2, join=True)
     _check_against_oracle(tmp_path)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: two GPUs")
-@pytest.mark.parametrize("mode", ["sharded", "replicated", "replicated_rs"])
+@pytest.mark.parametrize("mode", _MODES)
 def test_two_ranks_on_two_gpus_over_rccl_match_oracle(tmp_path, mode):
-    mp.spawn(_worker, args=(2, _port(), str(tmp_path), mode, "nccl"), nprocs=2, join=True)
+    m, lazy = _mode_args(mode)
+    mp.spawn(_worker, args=(2, _port(), str(tmp_path), m, "nccl", lazy), nprocs=2, join=True)
     _check_against_oracle(tmp_path)
 
 
@@ -150,12 +162,13 @@ def _nccl_world1_worker(rank, port, out_dir):
         out = {}
         # both forms of the loop: inside the library with RCCL called from C (the shipping path under backend nccl),
         # and in Python with torch.distributed collectives (ANIREC_DIST_NATIVE=0)
-        for mode, native in [(m, nv) for m in ("sharded", "replicated", "replicated_rs") for nv in ("1", "graph", "0")]:
+        for mode, native in [(m, nv) for m in _MODES for nv in ("1", "graph", "0")]:
             os.environ["ANIREC_DIST_NATIVE"] = "0" if native == "0" else "1"
             os.environ["ANIREC_DIST_GRAPH"] = "1" if native == "graph" else "0"
-            # (arena of 8: the graph variant replays one captured block of 4 steps, then runs the ragged fifth eagerly)
-            eng = DistTrainEngine(U.shape[0], A.shape[0], B, l2=1e-4, arena_steps=8, device=dev, mode=mode)
-            assert eng.loop and eng.eng.dense_mode == (1 if mode == "sharded" else 2)
+            mode, lazy = _mode_args(mode)
+            # (arena of 8: the graph variant replays two captured blocks of 4 steps, then runs the last three eagerly)
+            eng = DistTrainEngine(U.shape[0], A.shape[0], B, l2=1e-4, arena_steps=8, device=dev, mode=mode, lazy=lazy)
+            assert eng.loop and eng.eng.dense_mode == (1 if mode == "sharded" else 2) and eng.eng.lazy == lazy
             assert eng.native == (native != "0"), (mode, native)
             eng.set_head(w=1.2)
             eng.set_weights(U, A)
@@ -170,7 +183,7 @@ def _nccl_world1_worker(rank, port, out_dir):
             for k in ("w", "b", "gamma", "beta", "mov_mean", "mov_var"):
                 assert rec[k] == rref[k], (mode, k)
             assert abs(float(rec["last_loss"]) - float(rref["last_loss"])) < 2e-6
-            out[mode + native] = eng.epoch_metrics()[0]
+            out[mode + str(lazy) + native] = eng.epoch_metrics()[0]
             eng.close()
         assert max(out.values()) - min(out.values()) < 2e-6
         ref.close()
