@@ -185,6 +185,7 @@ def _train_leg(mode, data, tables, n_users, n_anime, B, K, W, inst, rank, world,
            "host_bound_frac": min(1.0, t_issue / dt), "stage_ms": kern_ms,
            "loop": "native (anirec_dist_run: RCCL from C)" if eng.native else "python (torch.distributed collectives)",
            "final_loss": float(rec["last_loss"]), "local_rows": int(e.rows),
+           "user_row_adam": "lazy" if e.lazy else "dense",
            "adam_rows": int(e.adam_rows[1] - e.adam_rows[0]) if (e.adam_rows[0] | e.adam_rows[1]) else int(e.rows),
            "dense_grad_bytes": int(e.dense_grad.numel() * 4) if e.dense_grad is not None else 0}
     eng.close()
@@ -207,10 +208,17 @@ def _run(args, rank, world, dev):
     head = _train_leg(mode, (ui, ai, t), (U, A), n_users, n_anime, B, K, W, inst, rank, world, dev)
     rows = head["adam_rows"] if mode != "sharded" else head["local_rows"]
     adam_bytes = bench.ADAM_BYTES_PER_ELEM * rows * 128
-    # dominant kernel: the dense Adam stream of this rank's rows (sharded: user part inside "mid"'s fork + anime part
-    # in "back"; measured here as the whole of both halves' Adam launches is not separable from the stream events,
-    # so the roofline is quoted on the full step instead)
-    step_bytes = adam_bytes + (bench.FWD_BYTES_PER_RATING + bench.BWD_BYTES_PER_RATING) * B
+    gather_bytes = (bench.FWD_BYTES_PER_RATING + bench.BWD_BYTES_PER_RATING) * B
+    dense_alg_bytes = adam_bytes + gather_bytes        # the dense update of every row this rank owns
+    if head["user_row_adam"] == "lazy":
+        # what the rank's step moves with lazy user rows: the gathers, the ~B touched user rows' W, M, V read and written
+        # twice (catch-up, sparse step), 1/8 of a 24 B/element flush pass over its user rows, the dense 28 B/element
+        # update of the replicated anime rows (an estimate from the launch shapes, not a counter)
+        n_local = rows - n_anime
+        step_bytes = (gather_bytes + 2 * min(B, n_local) * 128 * 4 * 3 * 2 + 24 * n_local * 128 / 8
+                      + bench.ADAM_BYTES_PER_ELEM * n_anime * 128)
+    else:
+        step_bytes = dense_alg_bytes
     gbs = step_bytes / (head["ms_per_step"] * 1e-3) / 1e9
     line = {
         "metric": "training_ratings_per_sec", "value": head["value"], "unit": "ratings/s",
@@ -221,15 +229,21 @@ def _run(args, rank, world, dev):
                                "(global %d), L2 1e-4, Keras-2.12 Adam, lr=lrfn(0)=1e-5"
                                % (args.workload, n_users, n_anime, B, B * world),
                    "global_batch": B * world,
-                   "parallelism": {"sharded": "dp%d by user: user table + Adam state sharded, anime table replicated "
-                                              "with dense RCCL all-reduce, head packets all-gathered" % world,
+                   "parallelism": {"sharded": "dp%d by user (mode `sharded`, the default — NOT north_star's literal "
+                                              "replicated tables, which is also.dp_modes.replicated): user table + Adam state "
+                                              "sharded with %s user-row Adam, anime table replicated with dense RCCL "
+                                              "all-reduce, head packets all-gathered" % (world, head["user_row_adam"]),
                                    "replicated": "dp%d replicated tables, dense all-reduce of both tables" % world,
                                    "replicated_rs": "dp%d replicated tables, reduce-scatter -> shard Adam -> all-gather"
                                                     % world}[mode]},
-        "roofline": {"kernel": "whole step of one rank (dense Adam over its %d rows + embedding fwd/bwd of its batch)" % rows,
+        "roofline": {"kernel": "whole step of one rank (%s Adam over its %d rows + embedding fwd/bwd of its batch; the "
+                               "collectives' wire time is inside the step time)" % (head["user_row_adam"], rows),
                      "bound": "hbm", "achieved": gbs, "peak": bench.HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": gbs / bench.HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms": head["ms_per_step"]},
+                     "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms": head["ms_per_step"],
+                     "vs_dense_algorithm": {"algorithmic_bytes_per_step": dense_alg_bytes,
+                                            "ratio_to_hbm_peak": dense_alg_bytes / (head["ms_per_step"] * 1e-3) / 1e9
+                                            / bench.HBM_PEAK_GBS}},
         "cpu_baseline": None,
         "host_issue_ms_per_step": head["host_issue_ms_per_step"], "host_bound_frac": head["host_bound_frac"],
         "step_loop": head["loop"],
@@ -267,7 +281,7 @@ def _run(args, rank, world, dev):
                     continue
                 modes[m] = _train_leg(m, (ui, ai, t), (U, A), n_users, n_anime, B, Kx, Wx, min(inst, 8), rank, world, dev)
             modes[mode] = {k: head[k] for k in ("value", "unit", "ms_per_step", "steps", "host_bound_frac", "stage_ms",
-                                                "adam_rows", "dense_grad_bytes")}
+                                                "adam_rows", "dense_grad_bytes", "user_row_adam")}
             line["also"]["dp_modes"] = modes
         except Exception as exc:                               # noqa: BLE001 - reported; the watchdog covers hangs
             line["also"]["dp_modes"] = {"error": "%s: %s" % (type(exc).__name__, exc)}

@@ -38,7 +38,7 @@ class TrainEngine:
         several at a time; tables and Adam state bit-identical to the dense update) — of ``run`` on one GPU (both
         tables) and of the user-sharded multi-GPU step (dense_mode 1: this rank's user rows; the replicated anime
         rows keep their dense update behind the all-reduce).  None = automatic: tables of at least 8 batches' worth of
-        rows on one GPU, user shards of at least 4 in mode 1 (below that most rows are touched every few steps and
+        rows on one GPU, user shards of at least 6 in mode 1 (below that most rows are touched every few steps and
         the plain dense stream is faster); ANIREC_LAZY_ADAM=0/1 overrides.  Never in dense_mode 2: that step is
         bound by its 188 MB collectives, not by the Adam stream."""
         self.lib = _lib.load()
@@ -76,7 +76,7 @@ class TrainEngine:
         if lazy is None:
             import os
             env = os.environ.get("ANIREC_LAZY_ADAM")
-            big = (self.rows >= 8 * self.max_batch) if self.dense_mode == 0 else (self.n_user_rows >= 4 * self.max_batch)
+            big = (self.rows >= 8 * self.max_batch) if self.dense_mode == 0 else (self.n_user_rows >= 6 * self.max_batch)
             lazy = (env != "0") and (env == "1" or big)
         self.lazy = bool(lazy) and ((self.dense_mode == 0 and self.n_seg == 1) or self.dense_mode == 1)
         self.lazy_state = (_dev_bytes(int(self.lib.anirec_train_lazy_bytes(self.rows)), dev) if self.lazy else None)

@@ -14,9 +14,9 @@ Inputs (tables, Adam moments, the synthetic ratings, the schedule) are resident 
 the timed region starts; the timed region contains everything a step needs: batch sort/chunk
 prep, fwd, head, bwd, dense Adam — K steps, barrier + synchronize on both sides, max over ranks.
 
-Prints ONE JSON line (rank 0) with `roofline` (dense fused Adam kernel, HBM-bound) and
-`cpu_baseline` (the plain-C oracle port of the reference's CPU TensorFlow step, timed on this
-box's host cores; N=1 only).
+Prints ONE JSON line (rank 0) with `roofline` (the dominant kernel of the timed path on the bytes it moves: the lazy
+flush at the S109M shape — VALU-bound, counters under profiles/ — or the dense fused Adam) and `cpu_baseline` (the
+plain-C oracle port of the reference's CPU TensorFlow step, timed on this box's host cores; N=1 only).
 """
 import argparse
 import json
@@ -183,41 +183,51 @@ def run_single(workload, steps, warmup, batch, use_graph=True, cpu_baseline=True
         "bwd_gbs": BWD_BYTES_PER_RATING * batch / (kern_ms["bwd"] * 1e-3) / 1e9,
     }
     if eng.lazy:
-        # the dominant kernel of the lazy path: ONE pass over W, M, V applies every row's pending steps of an 8-step
-        # window.  `achieved` is on the ALGORITHMIC bytes of SURVEY §8(d) — 28 B per element per step, i.e. what the
-        # dense update it replaces moves for those steps — so frac > 1 says how far under the dense algorithm's
-        # traffic the window runs; `moved_*` is what the pass really reads + writes (W, M, V once: 24 B per element).
+        # The dominant kernel of the lazy path: ONE pass over W, M, V applies every row's pending steps of an 8-step
+        # window.  `roofline` is on the bytes the pass MOVES (W, M, V read and written once: 24 B per element — the
+        # kernel's own algorithmic bytes; PMC traffic agrees to 1 %), so frac <= 1 by construction.  It is not what
+        # binds the kernel: the PMC passes (profiles/r04_pmc_valu_train_s109m.json) show its vector ALUs issuing 0.92
+        # of the kernel's cycles (`valu`), i.e. it is bound by the IEEE sqrt + divide arithmetic the bit-exact replay
+        # of Keras' Adam requires.  The ratio to SURVEY 8(d)'s dense-algorithm bytes (28 B x elements x steps covered)
+        # is a separate key, `vs_dense_algorithm`: > 1 says how far under the dense update's traffic the window runs.
         win = lazy_ms["launches"]["lazy_adam"] / max(1, lazy_ms["launches"]["lazy_flush"])
         fl_ms = lazy_ms["lazy_flush"]
         alg = adam_bytes * win
         moved = 24 * rows * 128
+        flush_name = "k_lazy_flush<true>" if dense_name == "k_adam<true>" else "k_lazy_flush<false>"
         out["lazy_kernels_ms"] = lazy_ms
         out["roofline"] = {"kernel": "k_lazy_flush (lazy dense Adam: every row's pending steps of a %d-step window in one "
-                                     "pass over W, M, V; IEEE sqrt + divide per element-step: VALU-bound)" % round(win),
-                           "bound": "hbm", "achieved": alg / (fl_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": alg / (fl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "traffic": pmc_traffic(tag, "k_lazy_flush<true>" if dense_name == "k_adam<true>" else "k_lazy_flush<false>",
-                                                  source="anirec_train.hip") if tag else None,
-                           "algorithmic_bytes_per_launch": alg, "avg_launch_ms": fl_ms, "steps_per_launch": win,
-                           "moved_bytes_per_launch": moved, "moved_gbs": moved / (fl_ms * 1e-3) / 1e9,
-                           "moved_frac": moved / (fl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "note": "frac > 1 is not a measurement error: `achieved` is on the bytes the DENSE algorithm of "
-                                   "SURVEY 8(d) would move for the %d steps one launch covers (28 B/element/step); the lazy "
-                                   "update applies those steps to every row in one pass, so it really moves 24 B/element per "
-                                   "launch (`moved_*`, `traffic`) and is bound by its IEEE sqrt + divide arithmetic.  Tables, "
-                                   "Adam moments and scalar state are bit-identical to the dense path "
-                                   "(dense_kernel_roofline) after every run() call, timed region included." % round(win)}
+                                     "pass over W, M, V; IEEE sqrt + divide per element-step)" % round(win),
+                           "bound": "hbm", "achieved": moved / (fl_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": moved / (fl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "traffic": pmc_traffic(tag, flush_name, source="anirec_train.hip") if tag else None,
+                           "algorithmic_bytes_per_launch": moved, "avg_launch_ms": fl_ms, "steps_per_launch": win,
+                           "limiter": "valu", "valu": pmc_valu(tag, flush_name) if tag else None,
+                           "vs_dense_algorithm": {"dense_bytes_for_the_steps_covered": alg,
+                                                  "equivalent_gbs": alg / (fl_ms * 1e-3) / 1e9,
+                                                  "ratio_to_hbm_peak": alg / (fl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                           "note": "achieved / frac: the 24 B per element the pass really moves over the kernel's mean "
+                                   "duration (in-kernel stamps over the instrumented steps).  The kernel is VALU-bound "
+                                   "(`valu`: counters of the committed PMC passes, null when the kernel source has "
+                                   "changed since): the replay performs the dense kernel's fp32 operations — tables, Adam "
+                                   "moments and scalar state are bit-identical to the dense path "
+                                   "(dense_kernel_roofline) after every run() call, timed region included."}
         per_step = (lazy_ms["fwd"] + lazy_ms["head"] + lazy_ms["bwd"] + lazy_ms["lazy_adam"]
                     + (fl_ms + lazy_ms["lazy_reduce"]) / win)
-        out["step_roofline"]["sum_of_kernels_ms"] = per_step
         # what the lazy step really moves: the gathers, ~15 000 touched rows x (W, M, V) read + written twice (catch-up,
         # sparse step), and 1/8 of the flush's pass
         touched = 2 * 15_000 * 128 * 4 * 3 * 2
         moved_step = (FWD_BYTES_PER_RATING + BWD_BYTES_PER_RATING) * batch + touched + moved / win
-        out["step_roofline"]["moved_bytes_per_step_estimate"] = moved_step
-        out["step_roofline"]["moved_frac"] = moved_step / (dt / steps) / 1e9 / HBM_PEAK_GBS
-        out["step_roofline"]["note"] = ("frac is on the dense algorithm's bytes (SURVEY 8(d)): above 1 because the lazy update "
-                                        "moves about a fifth of them (moved_frac)")
+        dense_alg = out["step_roofline"]
+        out["step_roofline"] = {"bound": "hbm", "moved_bytes_per_step_estimate": moved_step,
+                                "achieved": moved_step / (dt / steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": moved_step / (dt / steps) / 1e9 / HBM_PEAK_GBS,
+                                "sum_of_kernels_ms": per_step,
+                                "vs_dense_algorithm": {"algorithmic_bytes_per_step": dense_alg["algorithmic_bytes_per_step"],
+                                                       "equivalent_gbs": dense_alg["achieved"],
+                                                       "ratio_to_hbm_peak": dense_alg["frac"]},
+                                "note": "frac is on the bytes the lazy step moves (gathers + touched rows twice + 1/8 of the "
+                                        "flush pass); vs_dense_algorithm is the same step time on SURVEY 8(d)'s dense bytes"}
         out["dense_kernel_roofline"] = dense_roof
     else:
         out["roofline"] = dense_roof
@@ -261,7 +271,7 @@ def cpu_baseline_port(n_users, n_anime, batch, budget_s=12.0):
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense bf16/f16 MFMA peak (MI355X_MICROARCH.md)
 
 
-PMC_ROUND = "r03"
+PMC_ROUND = "r04"
 
 
 def git_blob_hash(path):
@@ -289,6 +299,23 @@ def pmc_traffic(name, kernels=None, source=None, calls=None):
         if calls:      # all launches of the listed kernels in one call of the op (the profiled script makes `calls` calls)
             return sum(d[k]["total_bytes_all_launches"] for k in kernels) / calls
         return sum(d[k]["total_bytes_per_launch"] * n for k, n in kernels.items())
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
+def pmc_valu(name, kernel):
+    """VALU evidence of one kernel from the committed SQ counter passes (profiles/<round>_pmc_valu_<name>.json, written
+    by scripts/pmc_valu_summary.py from three separate rocprofv3 --pmc passes): the share of the kernel's cycles its
+    vector ALUs were issuing, the shares of a wave's resident time spent issuing VALU work / parked on memory / stalled
+    at issue, the instruction count.  None when the kernel source has changed since the passes."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_valu_%s.json" % (PMC_ROUND, name))))
+        cur = git_blob_hash(os.path.join(ROOT, "anime_recommendations_amd", "csrc", "anirec_train.hip"))
+        if rec.get("sources", {}).get("anirec_train.hip") != cur:
+            return None
+        k = rec["kernels"][kernel]
+        return {x: k[x] for x in ("valu_pipe_busy", "valu_active_share", "wait_any_share", "wait_inst_share",
+                                  "valu_insts_per_wave", "effective_clock_ghz", "avg_us_under_pmc") if x in k}
     except (OSError, KeyError, ValueError, TypeError):
         return None
 
@@ -347,13 +374,17 @@ def _cosine_leg(W, nq, k, cpu_baseline, reps=3, slice_note=None, traffic_name=No
                         "frac": tfk / MFMA_F16_PEAK_TFLOPS, "kernel_ms": cand_ms,
                         "pipeline_frac": flops / dt / 1e12 / MFMA_F16_PEAK_TFLOPS, "traffic": traffic}}
     if allpairs:
+        # `achieved` / `frac` are what the matrix cores EXECUTED: the all-pairs job computes cosine(i, j) once for both
+        # rows across query batches, so the MFMA kernel runs executed_flops_share of SURVEY 8(d)'s 2 nq n D flops
+        # ("symmetry not exploited"); the figure on those algorithmic flops is kept under its own name
         rec["roofline"].update({
-            "executed_flops_share": work, "executed_tflops": tfk * work,
-            "executed_frac": tfk * work / MFMA_F16_PEAK_TFLOPS,
-            "note": "`achieved` / `frac` are on the ALGORITHMIC flops of SURVEY 8(d) (2 nq n D, symmetry not exploited); "
-                    "the all-pairs job computes cosine(i, j) once for both rows across query batches, so the MFMA "
-                    "kernel executes executed_flops_share of them (executed_*): lists bit-identical to the exact "
-                    "path and to the plain job (ANIREC_TOPK_SYM=0), which the tests compare row for row"})
+            "achieved": tfk * work, "frac": tfk * work / MFMA_F16_PEAK_TFLOPS, "executed_flops_share": work,
+            "algorithmic_equivalent_tflops": tfk, "algorithmic_equivalent_frac": tfk / MFMA_F16_PEAK_TFLOPS,
+            "note": "achieved / frac: the flops the MFMA kernel executed (executed_flops_share of 2 nq n D: every dot "
+                    "product across query batches is computed once for both rows) over the summed k_cand time; "
+                    "algorithmic_equivalent_* and pipeline_frac are the same times on the full 2 nq n D of SURVEY 8(d).  "
+                    "Lists are bit-identical to the exact path and to the plain job (ANIREC_TOPK_SYM=0), which the "
+                    "tests compare row for row"})
     if slice_note:
         rec["note"] = slice_note
     if cpu_baseline:
