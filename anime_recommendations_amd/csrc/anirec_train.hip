@@ -951,6 +951,15 @@ __device__ __forceinline__ void st_nt(float4 *p, const float4 &v) {
   const f4v x = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(x, reinterpret_cast<f4v *>(p));
 }
+// The same store as ONE opaque instruction: with __builtin_nontemporal_store (or the buffer-descriptor builtin) hipcc
+// allocates 160-166 VGPRs for the lazy flush — three waves per SIMD — against 128 with plain stores; the flush wants
+// the fourth wave's bytes in flight AND stores that leave the caches to the step kernels.  Nothing ever waits for a
+// store, so that hipcc does not count this one in vmcnt costs nothing (cdna_hip_programming.md 5.7: the trailing
+// s_nop keeps the next instruction off the data registers until the store has read them).
+__device__ __forceinline__ void st_nt_asm(float4 *p, const float4 &v) {
+  const f4v x = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
+}
 
 struct RowLoad {
   float4 w, m, v, p0;  // p0: first chunk partial (zero if the row is untouched)
@@ -1226,6 +1235,7 @@ struct LazyArgs {
   int tables;   // 2: both tables are updated lazily (one GPU); 1: the user rows only (user-sharded multi-GPU step: the
                 // replicated anime rows take their dense update behind the all-reduce every step)
   int lazy_rows;  // rows [0, lazy_rows) are the lazily updated ones (all rows, or the user rows)
+  int split;      // k_lazy_flush: workgroups [0, split) take the user rows, [split, grid) the anime rows
   unsigned long long *ticks;
 };
 
@@ -1259,7 +1269,7 @@ __device__ __forceinline__ float l2_only_grad(float w, float two_l2) {
 //    min / max (v_min3_f32 / v_max3_f32: 4 instructions instead of 8 compares + 7 s_and) and the row is tested ONCE,
 //    after its last step.  A NaN slips through min / max, but it is sticky (w NaN -> g, m, v NaN; m or v NaN -> w NaN),
 //    so one test of the final w catches it.
-//  * the square root is two exact-residual Newton corrections from v_rsq_f32 (sqrt4_normal) instead of v_sqrt_f32
+//  * the square root is ONE exact-residual Newton correction from v_rsq_f32 (sqrt4_normal) instead of v_sqrt_f32
 //    + both neighbours' residuals + a three-way selection (v_cmp + v_cndmask through VCC cost two wait states each
 //    on gfx950 that the compiler could only half fill: 494 s_nop in the round-3 kernel).
 //  * g = 2 lambda w without the "+ 0" of l2_only_grad: it only matters when the product is -0, and then the first
@@ -1285,14 +1295,16 @@ __device__ __forceinline__ Quad qfma(Quad x, Quad y, Quad z) {
   return {__builtin_elementwise_fma(x.a, y.a, z.a), __builtin_elementwise_fma(x.b, y.b, z.b)};
 }
 
-// Correctly rounded sqrt of x in [2^-96, 2^96] (no scaling of tiny inputs needed there): y = v_rsq_f32(x) (1 ulp),
-// s0 = x y, h = y / 2, then two Newton corrections with EXACT residuals (fma): s1 = s0 + (x - s0^2) h,
-// s = s1 + (x - s1^2) h.  6 packed operations + 1 transcendental per element, against 1 + 9 for the form the compiler
-// expands sqrtf into (v_sqrt_f32, both neighbours' residuals, a three-way selection).  That the last fma rounds
-// to the correctly rounded root for EVERY float of the range is not argued but checked: anirec_selftest_lazy_math
-// compares it with sqrtf on all 1.6e9 of them (tests/test_train_gpu.py), and the variant kOneStep — the same code cut
-// after the first correction — is there to show that the comparison can fail (it does, on ~1e8 inputs).
-template <bool kOneStep = false>
+// Correctly rounded sqrt of x in [2^-96, 2^96] (no scaling of tiny inputs needed there): y = v_rsq_f32(x),
+// s0 = x y, h = y / 2, then ONE Newton correction with the EXACT residual (fma): s = s0 + (x - s0^2) h.
+// 4 packed operations + 1 transcendental per element, against 1 + 9 for the form the compiler expands sqrtf into
+// (v_sqrt_f32, both neighbours' residuals, a three-way selection).  In general such a step is only faithful: that on
+// gfx950 — with this part's v_rsq_f32 — its fma rounds to the correctly rounded root for EVERY float of the range is
+// not argued but CHECKED: anirec_selftest_lazy_math compares it with sqrtf on all 1.6e9 of them
+// (tests/test_train_gpu.py: 0 mismatches; the same code without the correction, kSteps = 0, misses on 4.8e8 — the
+// comparison can fail; with a second correction, kSteps = 2, measured 0 as well and 7 % slower).  A part whose
+// transcendental unit rounded differently would fail that test, not silently change a table.
+template <int kSteps = 1>
 __device__ __forceinline__ Quad sqrt4_normal(Quad x) {
 #pragma clang fp contract(off)
   Quad y;
@@ -1301,10 +1313,11 @@ __device__ __forceinline__ Quad sqrt4_normal(Quad x) {
   y.b.x = __builtin_amdgcn_rsqf(x.b.x);
   y.b.y = __builtin_amdgcn_rsqf(x.b.y);
   const Quad s0 = x * y;
+  if (kSteps == 0) return s0;
   const Quad h = y * 0.5f;
   const Quad d0 = qfma(-s0, s0, x);
   const Quad s1 = qfma(d0, h, s0);
-  if (kOneStep) return s1;
+  if (kSteps == 1) return s1;
   const Quad d1 = qfma(-s1, s1, x);
   return qfma(d1, h, s1);
 }
@@ -1407,21 +1420,52 @@ __device__ __forceinline__ bool lazy_replay_path(Row3 &x, int j0, int j1, const 
   return lz_range_ok(rg) && t == t;
 }
 
+// The replay by the compiler's full expansions, OUT OF LINE: it runs for a handful of rows per table (a moment decayed
+// to a denormal, an exact zero) but, inlined, its 4 x 8 unrolled IEEE divides and square roots set the register
+// allocation of every kernel that can reach it (the flush: 150-166 VGPRs, three waves per SIMD).  Everything goes in
+// and out by value: an array whose address escaped into the call would live in scratch memory on the hot path too.
+struct SlowReplay {
+  Row3 x;
+  float sq[kLzWin];
+};
+struct AlphaPack {
+  float a[kLzWin];
+};
+__device__ __attribute__((noinline)) SlowReplay lazy_replay_slow(Row3 x, int j0, int j1, AlphaPack al, float two_l2) {
+  SlowReplay o;
+  float alpha[kLzWin], sq[kLzWin];
+#pragma unroll
+  for (int j = 0; j < kLzWin; ++j) {
+    alpha[j] = al.a[j];
+    sq[j] = 0.f;
+  }
+  (void)lazy_replay_path<false>(x, j0, j1, alpha, two_l2, sq);
+  o.x = x;
+#pragma unroll
+  for (int j = 0; j < kLzWin; ++j) o.sq[j] = sq[j];
+  return o;
+}
+
 // pending pure-L2 steps [j0, j1) (window-relative) of one row, a float4 per lane; sq[j] receives this lane's part of
 // sum(W_s^2), the weights step s READ.  The packed short sequences first; if any lane of the wave met an operand
 // outside their range, the whole replay is redone from the saved row with the compiler's expansions (rare: a moment
-// decayed to a denormal, an exact zero) — kept as a separate block so that the two never share registers.
+// decayed to a denormal, an exact zero).
 // (the row is re-read from memory for the redo — nothing has been stored yet — rather than kept in 12 more registers)
 __device__ __forceinline__ void lazy_replay(Row3 &x, int j0, int j1, const float (&alpha)[kLzWin], float two_l2,
                                             float (&sq)[kLzWin], const float *W, const float *M, const float *V,
                                             size_t e) {
   if (__all(lazy_replay_path<true>(x, j0, j1, alpha, two_l2, sq))) return;
-  x.w = reinterpret_cast<const float4 *>(W)[e];
-  x.m = reinterpret_cast<const float4 *>(M)[e];
-  x.v = reinterpret_cast<const float4 *>(V)[e];
+  Row3 y;
+  y.w = reinterpret_cast<const float4 *>(W)[e];
+  y.m = reinterpret_cast<const float4 *>(M)[e];
+  y.v = reinterpret_cast<const float4 *>(V)[e];
+  AlphaPack al;
 #pragma unroll
-  for (int j = 0; j < kLzWin; ++j) sq[j] = 0.f;
-  (void)lazy_replay_path<false>(x, j0, j1, alpha, two_l2, sq);
+  for (int j = 0; j < kLzWin; ++j) al.a[j] = alpha[j];
+  const SlowReplay o = lazy_replay_slow(y, j0, j1, al, two_l2);
+  x = o.x;
+#pragma unroll
+  for (int j = 0; j < kLzWin; ++j) sq[j] = o.sq[j];
 }
 
 __device__ __forceinline__ void lazy_alphas(const LazyArgs &a, int w0, int nj, float (&alpha)[kLzWin]) {
@@ -1543,24 +1587,31 @@ __global__ __launch_bounds__(256) void k_lazy_adam(LazyArgs a, AdamArgs d) {
 // whole window); per step and table the workgroup's sum(W_s^2) — recorded by the earlier kernels for the steps a row
 // had already taken, computed here for the replayed ones — goes to lzpart, the sum(W^2) of the weights as they are
 // left to the dense path's regpart (both parities: whichever step comes next reads it)
+// A workgroup only sees rows of ONE table (workgroups [0, split) stride over the user rows, the others over the anime
+// rows): one set of accumulators per thread instead of two.  106 VGPRs: four waves per SIMD, and those — not a row
+// prefetched into registers — cover the loads at the top of an iteration (round 3 kept the next row in flight in 12
+// more registers at three waves per SIMD: 9 MB in flight chip-wide, a latency-bound 3 TB/s; measured on one box,
+// same arithmetic: 262 us with the prefetch at 120 VGPRs, 253 us without).  The stores are non-temporal: with
+// plain stores the flush itself is 3 % faster and the step kernels behind it lose more than that (k_bwd +0.8 us,
+// k_lazy_reduce +3 us: the flush's dirty lines are what the caches then hold).
 template <bool kNT>
 __global__ __launch_bounds__(256) void k_lazy_flush(LazyArgs a) {
-  __shared__ float red[2 * kLzWin + 2][4];
+  __shared__ float red[kLzWin + 1][4];
   tick(a.ticks, 0);
   const int upto = a.state->step_fwd;
   const int w0 = a.w0[0];
   const int nj = upto - w0;
   const int l = threadIdx.x & 31;
-  const int nhw = gridDim.x * 8;
+  const int tab = (int)blockIdx.x < a.split ? 0 : 1;  // workgroup-uniform
+  const int row_lo = tab == 0 ? 0 : a.n_user_rows;
+  const int row_hi = tab == 0 ? min(a.n_user_rows, a.lazy_rows) : a.lazy_rows;
+  const int nhw = (tab == 0 ? a.split : (int)gridDim.x - a.split) * 8;
   float alpha[kLzWin];
   lazy_alphas(a, w0, nj, alpha);
-  float acc[2][kLzWin];
+  float acc[kLzWin];
 #pragma unroll
-  for (int j = 0; j < kLzWin; ++j) acc[0][j] = acc[1][j] = 0.f;
-  float fin[2] = {0.f, 0.f};
-  // one row per half-wave and iteration, the NEXT row's W / M / V and step word in flight while this one's pending
-  // steps are computed (8 steps x 4 elements of IEEE sqrt + divide: ~1 200 instructions per row — about as long as
-  // the row's memory time, so the two must overlap)
+  for (int j = 0; j < kLzWin; ++j) acc[j] = 0.f;
+  float fin = 0.f;
   auto load_row = [&](int r, Row3 &x) {
     const size_t e = (size_t)r * kRowVec + l;
     const float4 *Wp = reinterpret_cast<const float4 *>(a.W) + e, *Mp = reinterpret_cast<const float4 *>(a.M) + e,
@@ -1569,22 +1620,10 @@ __global__ __launch_bounds__(256) void k_lazy_flush(LazyArgs a) {
     x.m = kNT ? ld_nt(Mp) : *Mp;
     x.v = kNT ? ld_nt(Vp) : *Vp;
   };
-  int r = blockIdx.x * 8 + (threadIdx.x >> 5);
-  Row3 nx;
-  nx.w = nx.m = nx.v = make_float4(0.f, 0.f, 0.f, 0.f);
-  int ta_n = 0;
-  if (r < a.lazy_rows) {
-    ta_n = a.z.row_step[r];
-    load_row(r, nx);
-  }
-  for (; r < a.lazy_rows; r += nhw) {
-    Row3 x = nx;
-    const int ta = ta_n;
-    const int rn = r + nhw;
-    if (rn < a.lazy_rows) {
-      ta_n = a.z.row_step[rn];
-      load_row(rn, nx);
-    }
+  for (int r = row_lo + ((int)blockIdx.x - (tab == 0 ? 0 : a.split)) * 8 + (threadIdx.x >> 5); r < row_hi; r += nhw) {
+    Row3 x;
+    const int ta = a.z.row_step[r];
+    load_row(r, x);
     const int jt = ta - w0;  // steps [0, jt) of the window are on record, [jt, nj) are pending
     const size_t e = (size_t)r * kRowVec + l;
     float rec = 0.f;
@@ -1595,9 +1634,9 @@ __global__ __launch_bounds__(256) void k_lazy_flush(LazyArgs a) {
     if (jt < nj) {
       lazy_replay(x, jt, nj, alpha, a.two_l2, sq, a.W, a.M, a.V, e);
       if (kNT) {
-        st_nt(reinterpret_cast<float4 *>(a.W) + e, x.w);
-        st_nt(reinterpret_cast<float4 *>(a.M) + e, x.m);
-        st_nt(reinterpret_cast<float4 *>(a.V) + e, x.v);
+        st_nt_asm(reinterpret_cast<float4 *>(a.W) + e, x.w);
+        st_nt_asm(reinterpret_cast<float4 *>(a.M) + e, x.m);
+        st_nt_asm(reinterpret_cast<float4 *>(a.V) + e, x.v);
       } else {
         reinterpret_cast<float4 *>(a.W)[e] = x.w;
         reinterpret_cast<float4 *>(a.M)[e] = x.m;
@@ -1605,40 +1644,37 @@ __global__ __launch_bounds__(256) void k_lazy_flush(LazyArgs a) {
       }
       if (l == 0) a.z.row_step[r] = upto;
     }
-    const int tab = r < a.n_user_rows ? 0 : 1;
 #pragma unroll
-    for (int j = 0; j < kLzWin; ++j) {
-      const float add = sq[j] + (l == j ? rec : 0.f);  // lane parts of a replayed step, or the recorded row sum
-      if (tab == 0) acc[0][j] += add; else acc[1][j] += add;
-    }
-    const float fq = x.w.x * x.w.x + x.w.y * x.w.y + x.w.z * x.w.z + x.w.w * x.w.w;
-    if (tab == 0) fin[0] += fq; else fin[1] += fq;
+    for (int j = 0; j < kLzWin; ++j) acc[j] += sq[j] + (l == j ? rec : 0.f);  // a replayed step's lane parts, or the recorded row sum
+    fin += x.w.x * x.w.x + x.w.y * x.w.y + x.w.z * x.w.z + x.w.w * x.w.w;
   }
   // block sums in a fixed order: lanes -> waves -> the four waves
   const int wv = threadIdx.x >> 6;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int j = 0; j < kLzWin; ++j) {
-      const float v = wave_sum(acc[t][j]);
-      if ((threadIdx.x & 63) == 0) red[t * kLzWin + j][wv] = v;
-    }
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const float v = wave_sum(fin[t]);
-    if ((threadIdx.x & 63) == 0) red[2 * kLzWin + t][wv] = v;
+  for (int j = 0; j < kLzWin; ++j) {
+    const float v = wave_sum(acc[j]);
+    if ((threadIdx.x & 63) == 0) red[j][wv] = v;
+  }
+  {
+    const float v = wave_sum(fin);
+    if ((threadIdx.x & 63) == 0) red[kLzWin][wv] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 2 * kLzWin) {
-    const int t = threadIdx.x / kLzWin, j = threadIdx.x % kLzWin;
-    a.lzpart[((size_t)j * 2 + t) * ANIREC_ADAM_BLOCKS + blockIdx.x] =
-        ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
-  } else if (threadIdx.x < 2 * kLzWin + 2) {
-    const int t = threadIdx.x - 2 * kLzWin;
-    const float v = ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
-    if (t < a.tables) {  // (tables == 1: the anime partials belong to the dense launches of every step)
-      a.regpart[(size_t)(0 * 2 + t) * ANIREC_ADAM_BLOCKS + blockIdx.x] = v;
-      a.regpart[(size_t)(1 * 2 + t) * ANIREC_ADAM_BLOCKS + blockIdx.x] = v;
+  if (threadIdx.x <= kLzWin) {
+    const int j = threadIdx.x;
+    const float v = ((red[j][0] + red[j][1]) + red[j][2]) + red[j][3];
+    if (j < kLzWin) {  // the other table's slot of this workgroup is zero by definition
+      a.lzpart[((size_t)j * 2 + tab) * ANIREC_ADAM_BLOCKS + blockIdx.x] = v;
+      a.lzpart[((size_t)j * 2 + (tab ^ 1)) * ANIREC_ADAM_BLOCKS + blockIdx.x] = 0.f;
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t < a.tables) {  // (tables == 1: the anime partials belong to the dense launches of every step)
+          const float u = t == tab ? v : 0.f;
+          a.regpart[(size_t)(0 * 2 + t) * ANIREC_ADAM_BLOCKS + blockIdx.x] = u;
+          a.regpart[(size_t)(1 * 2 + t) * ANIREC_ADAM_BLOCKS + blockIdx.x] = u;
+        }
+      }
     }
   }
   tick(a.ticks, 1);
@@ -1772,7 +1808,7 @@ __global__ __launch_bounds__(256) void k_selftest_lazy_math(unsigned long long n
     x.a.y = __uint_as_float((uint32_t)min(b + 1, (unsigned long long)hi));
     x.b.x = __uint_as_float((uint32_t)min(b + 2, (unsigned long long)hi));
     x.b.y = __uint_as_float((uint32_t)min(b + 3, (unsigned long long)hi));
-    const Quad s = sqrt4_normal<kVar != 0>(x);
+    const Quad s = sqrt4_normal<kVar>(x);
     bad_s += __float_as_uint(s.a.x) != __float_as_uint(sqrtf(x.a.x));
     bad_s += __float_as_uint(s.a.y) != __float_as_uint(sqrtf(x.a.y));
     bad_s += __float_as_uint(s.b.x) != __float_as_uint(sqrtf(x.b.x));
@@ -2189,6 +2225,7 @@ static LazyArgs lazy_args(const anirec_train_desc *d, const TrainWs &w, int tick
   a.fuse_nb = 0;
   a.tables = lazy_users(d) ? 1 : 2;
   a.lazy_rows = lazy_users(d) ? d->n_user_rows : table_rows(d);
+  a.split = 0;
   a.ticks = ticks_of(w, ticks_slot);
   return a;
 }
@@ -2247,10 +2284,20 @@ static int lazy_step(const anirec_train_desc *d, const TrainWs &w, hipStream_t s
 }
 
 static int lazy_flush(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
+  LazyArgs a = lazy_args(d, w, 6);
+  const int grid = flush_grid(d);
+  // the grid's share of each table (a function of the table sizes only: the same partial slots every window)
+  a.split = grid;
+  if (a.tables == 2) {
+    long long sp = ((long long)grid * d->n_user_rows + table_rows(d) / 2) / table_rows(d);
+    if (sp < 1) sp = 1;
+    if (sp > grid - 1) sp = grid - 1;
+    a.split = (int)sp;
+  }
   if (stream_nt(d))
-    hipLaunchKernelGGL((k_lazy_flush<true>), dim3(flush_grid(d)), dim3(256), 0, s, lazy_args(d, w, 6));
+    hipLaunchKernelGGL((k_lazy_flush<true>), dim3(grid), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((k_lazy_flush<false>), dim3(flush_grid(d)), dim3(256), 0, s, lazy_args(d, w, 6));
+    hipLaunchKernelGGL((k_lazy_flush<false>), dim3(grid), dim3(256), 0, s, a);
   if (int te = ticks_collect(w, 6, s)) return te;
   hipLaunchKernelGGL(k_lazy_reduce, dim3(1), dim3(1024), 0, s, lazy_args(d, w, 7));
   if (int te = ticks_collect(w, 7, s)) return te;
@@ -2879,13 +2926,18 @@ int anirec_selftest_lazy_math(uint64_t n_div, uint64_t *counts2, void *stream) {
   if (!counts2) return ANIREC_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   ANIREC_HIP_CHECK(hipMemsetAsync(counts2, 0, 2 * sizeof(uint64_t), s));
-  // ANIREC_SELFTEST_BROKEN=1 (the test's own sanity leg): the square root cut after its first correction
-  const char *var = getenv("ANIREC_SELFTEST_BROKEN");
-  if (var && var[0] == '1')
-    hipLaunchKernelGGL(k_selftest_lazy_math<1>, dim3(8192), dim3(256), 0, s, (unsigned long long)n_div,
+  // ANIREC_SELFTEST_NEWTON=0|2 (the test's own sanity legs): the square root without its Newton correction (only
+  // faithful: the comparison must report misses) / with a second one, instead of the ONE the replay uses
+  const char *var = getenv("ANIREC_SELFTEST_NEWTON");
+  const int steps = var && (var[0] == '0' || var[0] == '2') ? var[0] - '0' : 1;
+  if (steps == 0)
+    hipLaunchKernelGGL(k_selftest_lazy_math<0>, dim3(8192), dim3(256), 0, s, (unsigned long long)n_div,
+                       reinterpret_cast<unsigned long long *>(counts2));
+  else if (steps == 2)
+    hipLaunchKernelGGL(k_selftest_lazy_math<2>, dim3(8192), dim3(256), 0, s, (unsigned long long)n_div,
                        reinterpret_cast<unsigned long long *>(counts2));
   else
-    hipLaunchKernelGGL(k_selftest_lazy_math<0>, dim3(8192), dim3(256), 0, s, (unsigned long long)n_div,
+    hipLaunchKernelGGL(k_selftest_lazy_math<1>, dim3(8192), dim3(256), 0, s, (unsigned long long)n_div,
                        reinterpret_cast<unsigned long long *>(counts2));
   return (int)hipGetLastError();
 }

@@ -309,8 +309,8 @@ def test_long_horizon_graph_run_tracks_the_c_oracle():
 
 
 def test_lazy_replay_square_root_is_sqrtf_on_every_float_of_its_range_and_divide_on_a_sample():
-    """The lazy update replays Adam steps with a short correctly rounded square root (v_rsq_f32 + two Newton
-    corrections with exact residuals) and the compiler's divide chain without its scaling / fix-up steps.  The square root is checked against
+    """The lazy update replays Adam steps with a short correctly rounded square root (v_rsq_f32 + one Newton
+    correction with an exact residual) and the compiler's divide chain without its scaling / fix-up steps.  The square root is checked against
     sqrtf on EVERY float of [2^-96, 2^96] (exhaustive: 1.6e9 inputs), the divide against IEEE `/` on 2^30 operand
     pairs of the admitted ranges: zero mismatches, i.e. inside its range test the replay performs exactly the dense
     kernel's fp32 operations (outside it, the dense kernel's own code runs)."""
@@ -321,15 +321,19 @@ def test_lazy_replay_square_root_is_sqrtf_on_every_float_of_its_range_and_divide
     _lib.check(lib.anirec_selftest_lazy_math(C.c_uint64(1 << 30), _lib.ptr(cnt), None), "anirec_selftest_lazy_math")
     torch.cuda.synchronize()
     assert cnt.tolist() == [0, 0], cnt.tolist()
-    # the comparison itself can fail: the same square root cut after its first Newton correction is only faithful
+    # the comparison itself can fail: the same code without its Newton correction (s0 = x * rsq(x)) is only faithful;
+    # with a second correction it must stay exact
     import os
-    os.environ["ANIREC_SELFTEST_BROKEN"] = "1"
-    try:
-        _lib.check(lib.anirec_selftest_lazy_math(C.c_uint64(0), _lib.ptr(cnt), None), "anirec_selftest_lazy_math")
-        torch.cuda.synchronize()
-    finally:
-        del os.environ["ANIREC_SELFTEST_BROKEN"]
-    assert cnt[0].item() > 1000 and cnt[1].item() == 0, cnt.tolist()
+    left = {}
+    for steps in ("0", "2"):
+        os.environ["ANIREC_SELFTEST_NEWTON"] = steps
+        try:
+            _lib.check(lib.anirec_selftest_lazy_math(C.c_uint64(0), _lib.ptr(cnt), None), "anirec_selftest_lazy_math")
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["ANIREC_SELFTEST_NEWTON"]
+        left[steps] = cnt.tolist()
+    assert left["0"][0] > 1_000_000 and left["0"][1] == 0 and left["2"] == [0, 0], left
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
@@ -342,6 +346,19 @@ def test_lazy_adam_is_bitwise_the_dense_update(use_graph):
     from anime_recommendations_amd.engine import TrainEngine
     n_u, n_a, B, steps = 5000, 900, 512, 77
     U, A, ui, ai, t = _problem(17, n_u, n_a, B * steps - 100, 1.1)
+    # rows the replay's short arithmetic sequences are NOT exact for — exact zeros, weights whose second moment is
+    # far below 2^-96, single tiny elements — take the out-of-line replay by the compiler's expansions: touched rows
+    # (catch-up + sparse step) and rows no batch ever touches (flush) alike
+    U[7] = 0.0
+    U[11] = 1e-30
+    U[13, ::3] = 0.0
+    A[5] = 0.0
+    A[6, 17] = 3e-33
+    never = np.setdiff1d(np.arange(n_u), np.unique(ui))[:3]
+    assert len(never) == 3
+    U[never[0]] = 0.0
+    U[never[1]] = -2e-31
+    U[never[2], 5] = 0.0
     n = len(ui)
     starts, counts, alphas = _schedule(n, B, 2e-4)
     engs = {}
