@@ -364,6 +364,7 @@ struct FwdArgs {
   int32_t *pk_count;
   float *su, *sa;
   int cap;
+  int32_t *touched;  // lazy dense Adam: [rows], step + 1 for every row the batch touches (or nullptr)
   unsigned long long *ticks;  // measurement hook: [gridDim.x][2] start / end stamps per workgroup, or nullptr
 };
 
@@ -406,7 +407,7 @@ __device__ __forceinline__ int ld_i32(const int32_t *p) {
 }
 
 // the forward pass of one workgroup: a half-wave per rating
-__device__ __forceinline__ void fwd_block(const FwdArgs &a, const anirec_step sc, int vblk) {
+__device__ __forceinline__ void fwd_block(const FwdArgs &a, const anirec_step sc, int vblk, int step) {
   const int nb = min(sc.count, a.cap);
   const int per_blk = blockDim.x >> 5;
   const int i = vblk * per_blk + (threadIdx.x >> 5);
@@ -425,12 +426,19 @@ __device__ __forceinline__ void fwd_block(const FwdArgs &a, const anirec_step sc
     a.pk_t[i] = t;
     a.su[i] = su;
     a.sa[i] = sa;
+    // lazy dense Adam: the batch's rows are marked HERE, two kernels before the catch-up of the next batch's rows
+    // (which rides in this step's head launch) asks which of them the sparse step of this batch will bring up to date
+    if (a.touched != nullptr) {
+      a.touched[ur] = step + 1;
+      a.touched[ar] = step + 1;
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void k_fwd(FwdArgs a) {
   tick(a.ticks, 0);
-  fwd_block(a, a.sched[a.state->step_fwd], blockIdx.x);
+  const int step = a.state->step_fwd;
+  fwd_block(a, a.sched[step], blockIdx.x, step);
   tick(a.ticks, 1);
 }
 
@@ -650,14 +658,7 @@ __device__ __forceinline__ void head_block(const HeadArgs &a, const HeadIn in, i
   }
 }
 
-__global__ __launch_bounds__(kHeadThreads) void k_head(HeadArgs a) {
-  __shared__ float scratch[kHeadCols * 16];
-  tick(a.ticks, 0);
-  const anirec_state *st = a.state;
-  const HeadIn in = {st->step_fwd, st->w, st->b, st->gamma, st->beta};
-  head_block(a, in, blockIdx.x, gridDim.x, scratch);
-  tick(a.ticks, 1);
-}
+// (k_head itself is defined below the lazy update's row kernels: its launch also carries their catch-up workgroups)
 
 // ------------------------------------------------------------------------------------
 // bwd: per-chunk weighted row sums
@@ -676,7 +677,6 @@ struct BwdArgs {
   const float *dy, *su, *sa;
   float *P, *S;
   int32_t *rowmap;
-  int32_t *touched;  // lazy dense Adam: [rows], step + 1 for every row the batch touches (or nullptr)
   int rowmap_lo;     // rows below it get no row-map word (user-sharded lazy mode: nobody would read or clear it)
   int arena_steps;
   unsigned long long *ticks;
@@ -816,7 +816,6 @@ __device__ __forceinline__ void bwd_chunk(const BwdArgs &a, const StepPub &pub, 
     a.S[pc] = ssum;
     if (rec.w > 0 && a.rowmap != nullptr && rec.x >= a.rowmap_lo)
       a.rowmap[(size_t)par * a.rows + rec.x] = ((gc << 10) | (rec.w - 1)) + 1;
-    if (rec.w > 0 && a.touched != nullptr) a.touched[rec.x] = pub.step + 1;
   }
 }
 
@@ -1206,7 +1205,7 @@ constexpr int kLzWin = ANIREC_LAZY_WINDOW;
 
 struct LazyState {
   int32_t *row_step;  // [rows] the step every row has been updated to (rows are current at the window's start)
-  int32_t *mark;      // [rows] t + 1 for the rows batch t touched (written by bwd(t))
+  int32_t *mark;      // [rows] t + 1 for the rows batch t touched (written by fwd(t))
   float *rowsq;       // [rows][kLzWin] sum(W_s^2) of the row for the window's steps it has already taken
 };
 __host__ __device__ inline LazyState lazy_carve(void *base, int rows) {
@@ -1231,11 +1230,12 @@ struct LazyArgs {
   size_t slot_bytes;
   int cap, capC, arena_steps;
   float *lzpart, *lzring, *regpart;
-  int fuse_nb;  // k_lazy_adam: > 0 = workgroups [fuse_nb, 2 fuse_nb) catch the rows of batch t + 1 up to step t + 1
   int tables;   // 2: both tables are updated lazily (one GPU); 1: the user rows only (user-sharded multi-GPU step: the
                 // replicated anime rows take their dense update behind the all-reduce every step)
   int lazy_rows;  // rows [0, lazy_rows) are the lazily updated ones (all rows, or the user rows)
   int split;      // k_lazy_flush: workgroups [0, split) take the user rows, [split, grid) the anime rows
+  int cu_lo;      // catch-up workgroups riding in another kernel's launch: they cover chunk-grid blocks [cu_lo, ...)
+  int n_sparse;   // k_lazy_adam: workgroups [0, n_sparse) take the sparse step, the others a catch-up slice
   unsigned long long *ticks;
 };
 
@@ -1531,8 +1531,31 @@ __global__ __launch_bounds__(256) void k_lazy_catchup(LazyArgs a) {
   tick(a.ticks, 1);
 }
 
+// head(t) — and, lazy dense Adam with the next batch already prepared (n_head < gridDim.x), beside it the catch-up of
+// the rows of batch t + 1 that batch t does NOT touch (fwd(t) marked its rows): workgroups [n_head, gridDim.x) bring
+// them up to step t + 1 while the forty head workgroups, bwd and the sparse step of batch t run — the rows are
+// disjoint from everything those read or write, so no order between them matters, and the next step starts at fwd.
+// (Step t itself is an L2-only step for them.)  Round 3 ran this catch-up as the second half of k_lazy_adam(t), on
+// the critical path behind bwd: 19 us for that launch; here it hides behind a head launch that used 40 of 256 CUs.
+__global__ __launch_bounds__(kHeadThreads) void k_head(HeadArgs a, LazyArgs z, int n_head) {
+  __shared__ float scratch[kHeadCols * 16];
+  tick(a.ticks, 0);
+  const anirec_state *st = a.state;
+  if ((int)blockIdx.x >= n_head) {
+    const int step = st->step_fwd, w0 = z.w0[0];
+    if (step + 1 < z.n_steps && step + 1 - w0 <= kLzWin)
+      lazy_catchup_row(z, step + 1, w0, z.cu_lo + (int)blockIdx.x - n_head, step + 1);
+    tick(a.ticks, 1);
+    return;
+  }
+  const HeadIn in = {st->step_fwd, st->w, st->b, st->gamma, st->beta};
+  head_block(a, in, blockIdx.x, n_head, scratch);
+  tick(a.ticks, 1);
+}
+
 // after bwd(t): step t on the rows the batch touched (chunk gradient - s W + 2 lambda W), the step finish in
 // workgroup 0.  Same operations, same order as the dense kernel's row_issue / row_finish for a touched row.
+// (the catch-up of batch t + 1's rows rides in k_head(t)'s launch)
 __global__ __launch_bounds__(256) void k_lazy_adam(LazyArgs a, AdamArgs d) {
   __shared__ float scratch[kHeadCols * 16];
   tick(a.ticks, 0);
@@ -1541,12 +1564,11 @@ __global__ __launch_bounds__(256) void k_lazy_adam(LazyArgs a, AdamArgs d) {
   const int w0 = a.w0[0];
   const float alpha = d.pub[par].alpha;
   const int l = threadIdx.x & 31;
-  if (a.fuse_nb > 0 && (int)blockIdx.x >= a.fuse_nb) {
-    // second half of the grid: the rows of batch t + 1 that batch t does NOT touch (bwd(t) marked its rows) are
-    // caught up to step t + 1 here, beside the sparse step — disjoint rows, so no order between the halves matters
-    // — and the next step starts at fwd.  (Step t itself is an L2-only step for them.)
+  if ((int)blockIdx.x >= a.n_sparse) {
+    // the slice of the next batch's catch-up that did not ride in head(t)'s launch (see k_head): disjoint rows, no
+    // order between it and the sparse step matters
     if (step + 1 < a.n_steps && step + 1 - w0 <= kLzWin)
-      lazy_catchup_row(a, step + 1, w0, (int)blockIdx.x - a.fuse_nb, step + 1);
+      lazy_catchup_row(a, step + 1, w0, a.cu_lo + (int)blockIdx.x - a.n_sparse, step + 1);
     tick(a.ticks, 1);
     return;
   }
@@ -2009,6 +2031,9 @@ static FwdArgs fwd_args(const anirec_train_desc *d, const TrainWs &w) {
   a.su = w.su;
   a.sa = w.sa;
   a.cap = d->max_batch;
+  a.touched = (d->lazy != 0 && d->lazy_state != nullptr && d->dense_mode != 2)
+                  ? lazy_carve(d->lazy_state, table_rows(d)).mark
+                  : nullptr;
   a.ticks = ticks_of(w, 0);
   return a;
 }
@@ -2048,9 +2073,34 @@ static inline int head_blocks(const anirec_train_desc *d) {
   return (d->max_batch + kHeadThreads - 1) / kHeadThreads * d->n_seg;
 }
 
-static int launch_head(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
+static LazyArgs lazy_args(const anirec_train_desc *d, const TrainWs &w, int ticks_slot);
+static inline int lazy_chunk_grid(const anirec_train_desc *d, const TrainWs &w);
+// The catch-up of the next batch's rows is cut in two slices of the chunk grid: blocks [0, head_share) ride in the
+// head launch, the rest beside the sparse step in k_lazy_adam's.  The user chunks come first in that grid and are
+// where the work is (the anime rows a batch touches are mostly current already).  Measured (S109M, one box,
+// fwd + head + bwd + lazy_adam by the in-kernel stamps): share 0 % (round 3's place: everything behind bwd) 37.9 us,
+// 35 % 34.8, 50 % 35.9, 65 % 36.2, 100 % 36.7 — the head launch, at the head's 109 VGPRs, holds four waves per
+// SIMD and its own forty workgroups leave it after 7 us; more than ~3 500 rows in it only move the tail from one
+// launch to the other.
+constexpr int kCatchupHeadPct = 35;
+static inline int catchup_head_share(const anirec_train_desc *d, const TrainWs &w) {
+  return (int)((long long)lazy_chunk_grid(d, w) * kCatchupHeadPct / 100);
+}
+
+// fuse_next (lazy update, the next batch's chunk table is in the arena): the launch also carries the catch-up
+// workgroups of that batch's rows
+static int launch_head(const anirec_train_desc *d, const TrainWs &w, hipStream_t s, bool fuse_next = false) {
   const HeadArgs a = head_args(d, w);
-  hipLaunchKernelGGL(k_head, dim3(head_blocks(d)), dim3(kHeadThreads), 0, s, a);
+  const int nh = head_blocks(d);
+  LazyArgs z;
+  memset(&z, 0, sizeof(z));
+  int extra = 0;
+  if (fuse_next && d->lazy != 0 && d->lazy_state != nullptr) {
+    z = lazy_args(d, w, 1);
+    z.ticks = nullptr;  // (the head's own stamps cover every workgroup of the launch)
+    extra = catchup_head_share(d, w);
+  }
+  hipLaunchKernelGGL(k_head, dim3(nh + extra), dim3(kHeadThreads), 0, s, a, z, nh);
   if (int te = ticks_collect(w, 1, s)) return te;
   return (int)hipGetLastError();
 }
@@ -2094,7 +2144,6 @@ static BwdArgs bwd_args(const anirec_train_desc *d, const TrainWs &w) {
   a.P = w.P;
   a.S = w.S;
   a.rowmap = d->rowmap;
-  a.touched = nullptr;
   a.rowmap_lo = 0;
   a.arena_steps = w.arena_steps;
   a.ticks = ticks_of(w, 2);
@@ -2103,12 +2152,11 @@ static BwdArgs bwd_args(const anirec_train_desc *d, const TrainWs &w) {
 
 static int launch_bwd_only(const anirec_train_desc *d, const TrainWs &w, hipStream_t s, bool lazy = false) {
   BwdArgs a = bwd_args(d, w);
-  if (lazy) {  // the lazy update walks the chunk table itself: no row map to fill (or to clear), but a mark per row
+  if (lazy) {  // the lazy update walks the chunk table itself: no row map to fill (or to clear)
     if (d->dense_mode == 1)
       a.rowmap_lo = d->n_user_rows;  // (user-sharded step: the densify pass still wants the anime rows' words)
     else
       a.rowmap = nullptr;
-    a.touched = lazy_carve(d->lazy_state, table_rows(d)).mark;
   }
   hipLaunchKernelGGL(k_bwd, dim3((2 * w.capC + 7) / 8), dim3(256), 0, s, a);
   if (int te = ticks_collect(w, 2, s)) return te;
@@ -2222,10 +2270,11 @@ static LazyArgs lazy_args(const anirec_train_desc *d, const TrainWs &w, int tick
   a.lzpart = w.lzpart;
   a.lzring = w.lzring;
   a.regpart = w.regpart;
-  a.fuse_nb = 0;
   a.tables = lazy_users(d) ? 1 : 2;
   a.lazy_rows = lazy_users(d) ? d->n_user_rows : table_rows(d);
   a.split = 0;
+  a.cu_lo = 0;
+  a.n_sparse = 0x7fffffff;
   a.ticks = ticks_of(w, ticks_slot);
   return a;
 }
@@ -2253,23 +2302,24 @@ static int lazy_begin(const anirec_train_desc *d, const TrainWs &w, int first_st
 }
 
 // catchup_first: the rows of this step's batch are not known to be current (first step of a run or of a prepared
-// block): a stand-alone catch-up launch.  fuse_next: the NEXT step's batch is already in the prep arena, so the sparse
-// launch also catches its rows up (second half of its grid) and the next step needs no catch-up launch.
+// block): a stand-alone catch-up launch.  fuse_next: the NEXT step's batch is already in the prep arena, so this step's
+// head launch also catches its rows up and the next step needs no catch-up launch.
 static int launch_lazy_catchup(const anirec_train_desc *d, const TrainWs &w, hipStream_t s) {
   hipLaunchKernelGGL(k_lazy_catchup, dim3(lazy_chunk_grid(d, w)), dim3(256), 0, s, lazy_args(d, w, 4));
   if (int e = ticks_collect(w, 4, s)) return e;
   return (int)hipGetLastError();
 }
 
-// the sparse step of the batch bwd has just processed (+ the catch-up of the next batch's rows when its chunk table
-// is already in the arena)
+// the sparse step of the batch bwd has just processed
 static int launch_lazy_adam(const anirec_train_desc *d, const TrainWs &w, hipStream_t s, bool fuse_next) {
   const int grid = lazy_chunk_grid(d, w);
   AdamArgs aa = adam_args(d, w);
   aa.ticks = nullptr;
   LazyArgs la = lazy_args(d, w, 5);
-  la.fuse_nb = fuse_next ? grid : 0;
-  hipLaunchKernelGGL(k_lazy_adam, dim3(fuse_next ? 2 * grid : grid), dim3(256), 0, s, la, aa);
+  la.n_sparse = grid;
+  la.cu_lo = catchup_head_share(d, w);
+  const int extra = fuse_next ? grid - la.cu_lo : 0;
+  hipLaunchKernelGGL(k_lazy_adam, dim3(grid + extra), dim3(256), 0, s, la, aa);
   if (int e = ticks_collect(w, 5, s)) return e;
   return (int)hipGetLastError();
 }
@@ -2278,7 +2328,7 @@ static int lazy_step(const anirec_train_desc *d, const TrainWs &w, hipStream_t s
   int e;
   if (catchup_first && (e = launch_lazy_catchup(d, w, s))) return e;
   if ((e = launch_fwd(d, w, s))) return e;
-  if ((e = launch_head(d, w, s))) return e;
+  if ((e = launch_head(d, w, s, fuse_next))) return e;
   if ((e = launch_bwd_only(d, w, s, true))) return e;
   return launch_lazy_adam(d, w, s, fuse_next);
 }
@@ -2494,12 +2544,12 @@ static int dist_front(anirec_dist_stepper *h, hipStream_t s, bool catchup_first)
 // mid — after the all-gather of the head packets: head, bwd, and the densify pass that feeds the gradient
 // collective.  User-sharded mode: the update of this rank's user rows needs nothing from the collective, so it is
 // forked onto the stepper's side stream right behind bwd and runs beside densify + all-reduce: the dense Adam stream
-// over the user rows, or — lazy user rows — the sparse step of the rows the batch touched (+ the catch-up of the next
-// batch's rows when `fuse_next`: its chunk table is in the arena).
+// over the user rows, or — lazy user rows — the sparse step of the rows the batch touched (the catch-up of the next
+// batch's rows rides in the head launch when `fuse_next`: its chunk table is in the arena).
 static int dist_mid(anirec_dist_stepper *h, hipStream_t s, bool fuse_next) {
   const bool lz = lazy_users(&h->d);
   int e;
-  if ((e = launch_head(&h->d, h->ws, s))) return e;
+  if ((e = launch_head(&h->d, h->ws, s, lz && fuse_next))) return e;
   if ((e = launch_bwd_only(&h->d, h->ws, s, lz))) return e;
   if (h->d.dense_mode == 1) {
     ANIREC_HIP_CHECK(hipEventRecord(h->fork, s));
