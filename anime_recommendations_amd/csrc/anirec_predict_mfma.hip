@@ -169,6 +169,18 @@ __global__ __launch_bounds__(256, 2) void k_predict_mfma(PredArgs a) {
 //   * sigmoid + store of tile t-1 are interleaved with the 96 MFMAs of tile t (second accumulator set):
 //     the store tail never runs on its own.
 // Requires n_anime % 4 == 0 (16-byte aligned row quads); other shapes take k_predict_mfma.
+//
+// Round 4, where the 100 k x 18 k grid's time goes (scripts/time_predict.py, interleaved rounds in one process; kDbg 1 =
+// epilogue + stores without the MFMAs, kDbg 2 = MFMAs without the stores):
+//   box A: whole kernel 1.50 ms (4.8 TB/s written), stores alone 1.30, MFMAs alone 1.43 (0.97 PFLOP/s on the
+//   1.38 TFLOP of the three-term split); box B: 1.71 ms (4.2 TB/s), stores alone 1.64, MFMAs alone 1.30.
+// The two sides are within 10 % of each other and of the whole (the overlap works), which of them is longer depends
+// on the box, and 35 % between boxes on the same binary is more than any kernel change below bought.
+// Built, measured and dropped: 64 users per wave (the wave's two LDS reads of an anime fragment feed twelve MFMAs
+// instead of six — the MFMA side is LDS-read-bound: every wave re-reads the whole 32 KB tile), a step covering half a
+// tile to stay inside 256 VGPRs, a user block's 32 anime leaving as 8 rows x 128 B per store instruction.
+// Bit-identical output; MFMAs alone 1.30 -> 1.17 ms, but stores alone 1.64 -> 1.87 ms (128-B row segments store at
+// 3.9 TB/s where 256-B segments reach 4.4 on that box) and the whole kernel 1.71 -> 1.92 ms.
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
