@@ -1479,28 +1479,34 @@ struct LanePool {
   hipEvent_t mid[kMaxLanes - 1] = {nullptr, nullptr, nullptr};  // chain l passed the stagger point of its first batch
   hipEvent_t cand_done[ANIREC_TOPK_MAX_BATCHES] = {};  // all-pairs job: batch b's last k_cand is behind this
 };
-static LanePool g_pool;
+// One pool per device of the process (a process that runs jobs on cuda:0 and then on cuda:1 gets two).  The side
+// streams and events of a pool are shared by every job on its device: g_pool_mu is held for the WHOLE enqueue of a
+// job (anirec_cosine_topk_job takes it), so two host threads — or two caller streams — never interleave their
+// event records; their jobs then run one after the other on the side streams, which is all a shared pool can offer.
+constexpr int kMaxPoolDevices = 16;
+static LanePool g_pools[kMaxPoolDevices];
 static std::mutex g_pool_mu;
 
+// (caller holds g_pool_mu)
 static int pool_get(LanePool **out) {
-  std::lock_guard<std::mutex> lk(g_pool_mu);
   int dev = 0;
   ANIREC_HIP_CHECK(hipGetDevice(&dev));
-  if (g_pool.device == dev) {
-    *out = &g_pool;
+  if (dev < 0 || dev >= kMaxPoolDevices) return ANIREC_ENODEVICE;
+  LanePool &pl = g_pools[dev];
+  if (pl.device == dev) {
+    *out = &pl;
     return ANIREC_OK;
   }
-  if (g_pool.device >= 0) return ANIREC_ENODEVICE;  // one process drives one GPU
   for (int i = 0; i < kMaxLanes - 1; ++i) {
-    ANIREC_HIP_CHECK(hipStreamCreateWithFlags(&g_pool.side[i], hipStreamNonBlocking));
-    ANIREC_HIP_CHECK(hipEventCreateWithFlags(&g_pool.join[i], hipEventDisableTiming));
-    ANIREC_HIP_CHECK(hipEventCreateWithFlags(&g_pool.mid[i], hipEventDisableTiming));
+    ANIREC_HIP_CHECK(hipStreamCreateWithFlags(&pl.side[i], hipStreamNonBlocking));
+    ANIREC_HIP_CHECK(hipEventCreateWithFlags(&pl.join[i], hipEventDisableTiming));
+    ANIREC_HIP_CHECK(hipEventCreateWithFlags(&pl.mid[i], hipEventDisableTiming));
   }
-  ANIREC_HIP_CHECK(hipEventCreateWithFlags(&g_pool.fork, hipEventDisableTiming));
+  ANIREC_HIP_CHECK(hipEventCreateWithFlags(&pl.fork, hipEventDisableTiming));
   for (int i = 0; i < ANIREC_TOPK_MAX_BATCHES; ++i)
-    ANIREC_HIP_CHECK(hipEventCreateWithFlags(&g_pool.cand_done[i], hipEventDisableTiming));
-  g_pool.device = dev;
-  *out = &g_pool;
+    ANIREC_HIP_CHECK(hipEventCreateWithFlags(&pl.cand_done[i], hipEventDisableTiming));
+  pl.device = dev;
+  *out = &pl;
   return ANIREC_OK;
 }
 
@@ -1681,7 +1687,9 @@ int anirec_cosine_topk_job(const float *What, int32_t n, const int32_t *queries,
     return ANIREC_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   LanePool *pool = nullptr;
+  std::unique_lock<std::mutex> pool_lock(g_pool_mu, std::defer_lock);
   if (lanes > 1 || sym) {
+    pool_lock.lock();  // until the job is enqueued (see g_pools)
     const int rc = pool_get(&pool);
     if (rc) return rc;
   }
@@ -1738,9 +1746,26 @@ int anirec_cosine_topk_job(const float *What, int32_t n, const int32_t *queries,
     ANIREC_HIP_CHECK(hipGetLastError());
     th_dev = theta0_dev;
   }
+  // from here on the side streams may hold work of this job: EVERY way out joins them back into the caller's
+  // stream first (an error return with un-joined side streams would let the caller reuse the workspace under them)
+  auto join_all = [&]() -> int {
+    if (lanes > 1) {
+      for (int l = 1; l < lanes; ++l) {
+        ANIREC_HIP_CHECK(hipEventRecord(pool->join[l - 1], pool->side[l - 1]));
+        ANIREC_HIP_CHECK(hipStreamWaitEvent(s, pool->join[l - 1], 0));
+      }
+    }
+    return ANIREC_OK;
+  };
   if (lanes > 1) {
     ANIREC_HIP_CHECK(hipEventRecord(pool->fork, s));
-    for (int l = 1; l < lanes; ++l) ANIREC_HIP_CHECK(hipStreamWaitEvent(pool->side[l - 1], pool->fork, 0));
+    for (int l = 1; l < lanes; ++l) {
+      const hipError_t we = hipStreamWaitEvent(pool->side[l - 1], pool->fork, 0);
+      if (we != hipSuccess) {
+        (void)join_all();
+        return (int)we;
+      }
+    }
   }
   // ANIREC_TOPK_STAGGER_PCT > 0 (experiment knob, default off): chain l starts its first batch when chain l-1 has
   // passed that share of the key stream of ITS first batch.
@@ -1754,7 +1779,13 @@ int anirec_cosine_topk_job(const float *What, int32_t n, const int32_t *queries,
     const int q0 = starts_host[b], cnt = starts_host[b + 1] - q0;
     hipEvent_t mid = nullptr;
     if (i < lanes && stagger > 0 && lanes > 1) {
-      if (l > 0) ANIREC_HIP_CHECK(hipStreamWaitEvent(st, pool->mid[l - 1], 0));
+      if (l > 0) {
+        const hipError_t we = hipStreamWaitEvent(st, pool->mid[l - 1], 0);
+        if (we != hipSuccess) {
+          (void)join_all();
+          return (int)we;
+        }
+      }
       if (l + 1 < lanes && i + 1 < n_batches - learn_batches) mid = pool->mid[l];
     }
     SymPlan sp;
@@ -1782,15 +1813,12 @@ int anirec_cosine_topk_job(const float *What, int32_t n, const int32_t *queries,
     const int rc = run_batch(What, Wb, n, queries + q0, cnt, exclude_self, k, th_imm, th_dev, lb[l], unnorm, false,
                              out_idx + (size_t)q0 * k, out_score + (size_t)q0 * k, flags_out + q0, mode, nullptr, st, mid,
                              stagger, sym ? &sp : nullptr);
-    if (rc) return rc;
-  }
-  if (lanes > 1) {
-    for (int l = 1; l < lanes; ++l) {
-      ANIREC_HIP_CHECK(hipEventRecord(pool->join[l - 1], pool->side[l - 1]));
-      ANIREC_HIP_CHECK(hipStreamWaitEvent(s, pool->join[l - 1], 0));
+    if (rc) {
+      (void)join_all();
+      return rc;
     }
   }
-  return ANIREC_OK;
+  return join_all();
 }
 
 // ------------------------------------------------------------------------------------------------

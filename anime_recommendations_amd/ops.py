@@ -112,10 +112,15 @@ _JOB_WS = {}
 
 
 def _job_workspace(nbytes, dev):
-    """The job's workspace, kept between calls (grow-only, one per device and stream): at 350 k rows it is several GB,
-    and torch's caching allocator may carve a freed block of that size up for the next small allocations, so that the
-    following job pays a hipMalloc inside its call.  Stream-ordered reuse is safe: every job runs on torch's current
-    stream and ends joined to it.  ``release_workspaces`` drops it."""
+    """The job's workspace, kept between calls (grow-only, one per device and stream): at 350 k rows it is several GB
+    (the all-pairs job: two inboxes of n x 256 x 8 B = 1.4 GB, two chains' logs of ~2 GB each, the candidate buffers —
+    7-8 GB in all), and torch's caching allocator may carve a freed block of that size up for the next small
+    allocations, so that the following job pays a hipMalloc inside its call.  Stream-ordered reuse is safe: every job
+    runs on torch's current stream and ends joined to it.  ``release_workspaces`` drops the cache; a workspace larger
+    than ANIREC_TOPK_WS_CACHE_GB (default 16) is never cached."""
+    cap = float(os.environ.get("ANIREC_TOPK_WS_CACHE_GB", "16")) * (1 << 30)
+    if nbytes > cap:
+        return torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
     key = (torch.device(dev).index, torch.cuda.current_stream(dev).cuda_stream)
     ws = _JOB_WS.get(key)
     if ws is None or ws.numel() < nbytes:
@@ -222,6 +227,12 @@ def cosine_topk_mfma(What, queries, k, exclude_self=True, keep=None, batch=None,
                 and (allpairs is True or (n >= 196608
                                           and bool(torch.equal(q, torch.arange(n, dtype=torch.int32, device=dev))))))
     if want_sym and allpairs == "auto" and os.environ.get("ANIREC_TOPK_PILOT", "1") != "0":
+        if batch is None:
+            # size the cached workspace for the job that follows BEFORE the pilot's small job takes the slot (a cold
+            # call would otherwise allocate the pilot's workspace, drop it and allocate the main one)
+            st0, _, ln0 = topk_allpairs_plan(n, k, lanes)
+            rows0 = max(st0[i + 1] - st0[i] for i in range(len(st0) - 1))
+            _job_workspace(int(lib.anirec_cosine_topk_allpairs_workspace_bytes(n, rows0, max(1, min(ln0, 2)))), dev)
         want_sym = _allpairs_pilot(What, n, k + int(bool(exclude_self)), stats)
     if want_sym and batch is None:
         starts, learn, lanes = topk_allpairs_plan(n, k, lanes)

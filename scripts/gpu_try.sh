@@ -1,7 +1,11 @@
 #!/bin/bash
-# round-4 evidence for the training path: kernel stats + traffic (collect_profiles) + the VALU counter passes
 set -u
-bash scripts/collect_profiles.sh r04 train train7m
-bash scripts/pmc_valu.sh r04
-timeout -k 10 300 python bench.py --no-also > gpurun_out/r04_bench_train_only.json 2> gpurun_out/r04_bench_train_only.err
+mkdir -p gpurun_out
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/r04_gputests.log 2>&1
+echo "tests rc=$?" >> gpurun_out/r04_gputests.log
+tail -5 gpurun_out/r04_gputests.log
+timeout -k 10 600 python bench.py > gpurun_out/r04_bench_line.json 2> gpurun_out/r04_bench_line.err
 echo "bench rc=$?"
+timeout -k 10 600 python scripts/time_dist_shape.py 1 2 4 8 > gpurun_out/r04_dist_shape.txt 2>&1
+echo "shape rc=$?"
+grep "^G" gpurun_out/r04_dist_shape.txt
