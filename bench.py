@@ -268,7 +268,7 @@ def cpu_baseline_port(n_users, n_anime, batch, budget_s=12.0):
                       "CPU step; TensorFlow 2.12 is not installable offline)" % (n, batch, n_users, n_anime)}
 
 
-MFMA_F16_PEAK_TFLOPS = 2500.0   # dense bf16/f16 MFMA peak (MI355X_MICROARCH.md)
+MFMA_F16_PEAK_TFLOPS = 2500.0   # dense f16 (= bf16) MFMA peak (MI355X_MICROARCH.md); the kernels use v_mfma_f32_16x16x32_f16
 
 
 PMC_ROUND = "r04"

@@ -133,6 +133,37 @@ def test_350k_neighbour_lists_properties_and_sample_equals_exact_path():
     assert (es.cpu().numpy() == sim[[0, 5, 17, 999, 4095]]).all()
 
 
+def test_anime_18k_allpairs_top100_all_queries_equal_exact_path():
+    """BASELINE configs[3], anime leg, exactly as bench.py runs it: ALL 18 000 rows as queries against all 18 000
+    keys, k = 100 (the plan this size takes: one batch, 128-row workgroups, key-range splits) — every list has k
+    distinct neighbours in descending order without the query, no row falls back, and 640 rows (first, last, a
+    planted duplicate pair, a random sample) equal the exact kernels' lists and scores bit for bit."""
+    from anime_recommendations_amd import ops
+    n = 18_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    W = torch.randn(n, 128, generator=g, device="cuda") * 0.05
+    W[7777] = W[42]                                    # an exact duplicate pair: score 1, tie order by index
+    Wh = ops.rownorm(W)
+    q = torch.arange(n, dtype=torch.int32, device="cuda")
+    stats = {}
+    idx, sim, nfb = ops.cosine_topk_mfma(Wh, q, 100, stats=stats)
+    assert nfb == 0 and stats["batches"] == 1
+    idx_h, sim_h = idx.cpu().numpy(), sim.cpu().numpy()
+    assert (idx_h >= 0).all() and (idx_h != np.arange(n)[:, None]).all()
+    assert (np.diff(sim_h, axis=1) <= 0).all()
+    tie = np.diff(sim_h, axis=1) == 0
+    assert (np.diff(idx_h, axis=1)[tie] > 0).all()
+    assert idx_h[42, 0] == 7777 and idx_h[7777, 0] == 42
+    assert (np.sort(idx_h, axis=1)[:, 1:] != np.sort(idx_h, axis=1)[:, :-1]).all()          # no repeats in any row
+    rng = np.random.default_rng(5)
+    rows = np.unique(np.concatenate([[0, 42, 7777, n - 1], rng.choice(n, 640, replace=False)]))
+    sample = torch.from_numpy(rows.astype(np.int32)).cuda()
+    ei, es = ops.cosine_topk(Wh, sample, 100)
+    assert (ei.cpu().numpy() == idx_h[rows]).all()
+    assert (es.cpu().numpy() == sim_h[rows]).all()
+
+
 def test_350k_allpairs_top100_rows_of_every_batch_equal_the_exact_path():
     """BASELINE configs[3] users job exactly as bench.py runs it (350 k x 350 k, k = 100, the library's all-pairs plan:
     a 16 384-row learning batch, then batches of equal work on two interleaved chains, each computing its dot products

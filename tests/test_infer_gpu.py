@@ -114,7 +114,7 @@ def test_predict_pairs_grid_topk_match_oracle():
 
 @pytest.mark.parametrize("n,nq,k", [(1000, 1000, 10), (5000, 700, 100), (17560, 2048, 100), (333, 333, 127)])
 def test_mfma_topk_equals_exact_path_bitwise(n, nq, k):
-    """bf16-MFMA candidates + exact fp32 re-rank must reproduce the exact kernels' lists exactly."""
+    """f16-MFMA candidates + exact fp32 re-rank must reproduce the exact kernels' lists exactly."""
     from anime_recommendations_amd import ops
     rng = np.random.default_rng(10)
     W = rng.normal(0, 0.05, (n, 128)).astype(np.float32)
