@@ -19,7 +19,7 @@ CHUNK = 32
 ADAM_BLOCKS = 8192
 MAX_TOPK = 128
 MAX_SEG = 16
-ABI_VERSION = 3
+ABI_VERSION = 4
 TOPK_MAX_BATCHES = 64
 RCCL_ID_BYTES = 128
 LAZY_WINDOW = 8

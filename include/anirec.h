@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ANIREC_ABI_VERSION 3
+#define ANIREC_ABI_VERSION 4
 #define ANIREC_DIM 128          /* embedding width (floats) */
 #define ANIREC_MAX_BATCH 16384  /* ratings per rank per step handled by one sort workgroup */
 #define ANIREC_CHUNK 32         /* max gradient contributions summed by one half-wave */
