@@ -198,8 +198,8 @@ int anirec_dist_step_mid(anirec_dist_stepper *h, void *stream);
 int anirec_dist_step_back(anirec_dist_stepper *h, void *stream);
 /* LAZY USER ROWS (desc->lazy != 0 with dense_mode 1; see LAZY DENSE ADAM below).  In the user-sharded step the dense
  * Adam stream over the rank's user rows becomes: sparse step of the rows the batch touched (forked beside densify +
- * all-reduce, with the catch-up of the next batch's rows), a flush of the user rows every ANIREC_LAZY_WINDOW steps and
- * at the end of a run.  The replicated anime rows keep their dense update behind the all-reduce.  Tables, Adam moments
+ * all-reduce; the catch-up of the next batch's rows rides partly in the head launch, partly in that forked launch), a
+ * flush of the user rows every ANIREC_LAZY_WINDOW steps and at the end of a run.  The replicated anime rows keep their dense update behind the all-reduce.  Tables, Adam moments
  * and scalar state stay bit-identical to the dense step; reg_user_wsum / loss_wsum receive the user rows' L2 term at
  * the flush.  A caller that drives the steps itself must tell the stepper where it is: _begin(first_step, n_steps)
  * once per run (the tables are current there; stream-ordered) and _block(n) after every anirec_train_prep of n steps;
@@ -232,7 +232,9 @@ int anirec_dist_run(anirec_dist_stepper *h, anirec_dist_comm *c, int32_t first_s
  * gives every row a gradient (2 lambda W) — 28 B/element/step of HBM traffic for rows the batch never touched.  Each
  * element's update sequence is independent of every other element's, so the rows a batch does not touch can take
  * their pure-L2 steps LATER, several at a time, in registers, with the same fp32 operations in the same order:
- *   catch-up(t)  brings the rows batch t touches up to step t (their pending L2-only steps), before fwd(t) reads them;
+ *   catch-up(t)  brings the rows batch t touches up to step t (their pending L2-only steps), before fwd(t) reads them
+ *                (extra workgroups of step t-1's head and sparse-adam launches; fwd(t-1) marks which rows batch t-1
+ *                itself will bring up to date);
  *   sparse adam(t) applies step t (chunk gradient + 2 lambda W) to those rows only;
  *   every ANIREC_LAZY_WINDOW steps (and at the end of every anirec_trainer_run call) a flush replays the pending
  *   steps of every row — one streaming pass over W, M, V per window instead of one per step — and a reduce kernel
