@@ -92,8 +92,9 @@ __device__ __forceinline__ int4 ld4(const int32_t *p, int64_t i, int64_t n, int3
 
 // first / last row of every user (all rows with a valid id, whatever their other columns hold).  A lane reads 4
 // consecutive rows; only the first row of a run of equal ids updates the first-row table and only the last row
-// of a run the last-row table, and both read before they update (a stale read only costs a redundant atomic).
+// of a run the last-row table.
 constexpr int kSpanIters = 4;
+constexpr int kFewHeads = 8;  // lanes of a wave with a run end among their rows: up to here the atomics go out unread
 __global__ __launch_bounds__(256) void k_ing_span(const int32_t *user, int64_t n, int bound, int32_t *ufirst,
                                                   int32_t *ulast) {
   const int lane = lane_id();
@@ -111,14 +112,36 @@ __global__ __launch_bounds__(256) void k_ing_span(const int32_t *user, int64_t n
     for (int j = 0; j < 4; ++j)
       if (v[j] < 0 || v[j] >= bound) v[j] = -1;
     const int32_t left = __shfl_up(v[3], 1, 64), right = __shfl_down(v[0], 1, 64);
+    bool head[4], tail[4];
+    bool any = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (v[j] < 0) continue;
-      const int32_t i = (int32_t)(i0[k] + j);
-      const bool head = j ? v[j] != v[j - 1] : (lane == 0 || v[0] != left);
-      const bool tail = j < 3 ? v[j] != v[j + 1] : (lane == 63 || v[3] != right);
-      if (head && ufirst[v[j]] > i) atomicMin(&ufirst[v[j]], i);
-      if (tail && ulast[v[j]] < i) atomicMax(&ulast[v[j]], i);
+      head[j] = v[j] >= 0 && (j ? v[j] != v[j - 1] : (lane == 0 || v[0] != left));
+      tail[j] = v[j] >= 0 && (j < 3 ? v[j] != v[j + 1] : (lane == 63 || v[3] != right));
+      any |= head[j] | tail[j];
+    }
+    if (__popcll(__ballot(any)) <= kFewHeads) {
+      // a table grouped by user: a handful of run ends per wave — atomics without a return value, nothing to wait for
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int32_t i = (int32_t)(i0[k] + j);
+        if (head[j]) atomicMin(&ufirst[v[j]], i);
+        if (tail[j]) atomicMax(&ulast[v[j]], i);
+      }
+    } else {
+      // no runs: read before updating (a stale read only costs a redundant atomic), the eight reads in flight together
+      int32_t f[4], l[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f[j] = ufirst[head[j] ? v[j] : 0];
+        l[j] = ulast[tail[j] ? v[j] : 0];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int32_t i = (int32_t)(i0[k] + j);
+        if (head[j] && f[j] > i) atomicMin(&ufirst[v[j]], i);
+        if (tail[j] && l[j] < i) atomicMax(&ulast[v[j]], i);
+      }
     }
   }
 }
@@ -127,11 +150,15 @@ struct RowVals {
   int32_t u, a, s, e;
   double r;
 };
-__device__ __forceinline__ uint64_t row_hash(const RowVals &v) {
-  uint64_t h = mix64(((uint64_t)(uint32_t)v.u << 32) | (uint32_t)v.a);
-  h = mix64(h ^ rating_bits(v.r));
-  h = mix64(h ^ (((uint64_t)(uint32_t)v.s << 32) | (uint32_t)v.e));
-  return h;
+// 32 bits for the chunk's LDS table (slot = the low bits, tag = bits 13..30).  Three 32-bit multiplies: the
+// 64-bit mixer of the list path is six 64-bit multiplies per row — a quarter of the front pass's issue time on a part whose
+// integer multiplier runs at quarter rate.  Rows that meet here share their user; the anime id carries the spread.
+__device__ __forceinline__ uint32_t row_hash32(const RowVals &v) {
+  const uint64_t rb = rating_bits(v.r);
+  uint32_t h = ((uint32_t)v.a * 0x9E3779B1u) ^ (uint32_t)v.u;
+  h = ((h ^ (h >> 15)) * 0x85EBCA77u) ^ (uint32_t)v.e ^ ((uint32_t)v.s << 24) ^ (uint32_t)rb ^ (uint32_t)(rb >> 32);
+  h = (h ^ (h >> 13)) * 0xC2B2AE3Du;
+  return h ^ (h >> 16);
 }
 __device__ __forceinline__ bool row_eq(const IngestCols &c, const RowVals &v, int64_t j) {
   return v.u == c.user[j] && v.a == c.anime[j] && v.s == c.status[j] && v.e == c.episodes[j] &&
@@ -235,9 +262,9 @@ __global__ __launch_bounds__(kFrontThreads, 2) void k_ing_front(FrontArgs a) {
         if ((int64_t)F[b][j] < base || (int64_t)L[b][j] >= base + kChunk) continue;  // non-local: the list
         meta[h + b][j] = (uint16_t)(kOk | kLocal | (uint32_t)(F[b][j] - base));
         const RowVals v{u[j], an[j], st[j], ep[j], R[b][j]};
-        const uint64_t hh = row_hash(v);
-        const uint32_t entry = ((uint32_t)(hh >> 32) & 0x7FFFE000u) | (uint32_t)ridx;
-        uint32_t s = (uint32_t)hh & (kLdsSlots - 1);
+        const uint32_t hh = row_hash32(v);
+        const uint32_t entry = (hh & 0x7FFFE000u) | (uint32_t)ridx;
+        uint32_t s = hh & (kLdsSlots - 1);
         for (;;) {
           const uint32_t old = atomicCAS(&tab[s], kLdsEmpty, entry);
           if (old == kLdsEmpty) break;
@@ -636,15 +663,27 @@ __global__ __launch_bounds__(256) void k_enc_first(const int32_t *id, int64_t n,
         bad |= i0[k] + j < n;
         v[j] = -1;
       }
-    // A table grouped by user presents runs of equal ids: only the first row of a run goes to memory, and it
-    // reads before it updates (a stale read only costs a redundant atomic), so that after its first few rows an
-    // id costs no atomic at all.
+    // A table grouped by user presents runs of equal ids: only the first row of a run goes to memory — as an
+    // atomic without a return value (a few per wave, nothing waits for them).  A column without runs reads before
+    // it updates (a stale read only costs a redundant atomic; after its first few rows an id costs no atomic at
+    // all), the four reads in flight together.
     const int32_t left = __shfl_up(v[3], 1, 64);
+    bool head[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bool head = j ? v[j] != v[j - 1] : (lane == 0 || v[0] != left);
-      const int32_t i = (int32_t)(i0[k] + j);
-      if (head && v[j] >= 0 && first[v[j]] > i) atomicMin(&first[v[j]], i);
+    for (int j = 0; j < 4; ++j) head[j] = v[j] >= 0 && (j ? v[j] != v[j - 1] : (lane == 0 || v[0] != left));
+    if (__popcll(__ballot(head[0] | head[1] | head[2] | head[3])) <= kFewHeads) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (head[j]) atomicMin(&first[v[j]], (int32_t)(i0[k] + j));
+    } else {
+      int32_t f[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f[j] = first[head[j] ? v[j] : 0];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int32_t i = (int32_t)(i0[k] + j);
+        if (head[j] && f[j] > i) atomicMin(&first[v[j]], i);
+      }
     }
   }
   if (bad) *err = 1;
@@ -738,6 +777,102 @@ __global__ __launch_bounds__(256) void k_enc_emit(const int32_t *id, int64_t n, 
         if (i0[k] + j < n) idx[i0[k] + j] = r[j];
     }
   }
+}
+
+// Small id spaces (the anime column: 18 k ids without runs): a gather per row from a 72 KB global table misses the
+// CU's vector cache nearly every time, and the column then moves at a tenth of what HBM delivers.  Up to
+// kEncLdsIds ids the table lives in LDS instead: one workgroup per CU owns a contiguous, ascending range of the rows,
+// finds its own first appearances with LDS atomics and merges the few that beat the global table at the end; the
+// emit pass maps the column through an LDS copy of the rank table.
+constexpr int kEncLdsIds = 32768;  // 128 KB of LDS
+constexpr int kEncLdsThreads = 1024;
+constexpr int kEncLdsIters = 4;    // 16-byte loads in flight per lane
+__device__ __forceinline__ void enc_lds_range(int64_t n, int64_t &lo, int64_t &hi) {
+  const int64_t groups = (n + 3) / 4;
+  const int64_t per = (groups + gridDim.x - 1) / gridDim.x;
+  const int64_t g0 = (int64_t)blockIdx.x * per, g1 = g0 + per;
+  lo = (g0 < groups ? g0 : groups) * 4;
+  hi = (g1 < groups ? g1 : groups) * 4;
+}
+__global__ __launch_bounds__(kEncLdsThreads) void k_enc_first_lds(const int32_t *id, int64_t n, int bound, int32_t *first,
+                                                                  int32_t *err) {
+  __shared__ int32_t tab[kEncLdsIds];
+  for (int v = threadIdx.x; v < bound; v += kEncLdsThreads) tab[v] = 0x7FFFFFFF;
+  __syncthreads();
+  int64_t lo, hi;
+  enc_lds_range(n, lo, hi);
+  bool bad = false;
+  for (int64_t i = lo + (int64_t)threadIdx.x * 4; i < hi; i += (int64_t)kEncLdsThreads * 4 * kEncLdsIters) {
+    int4 q[kEncLdsIters];
+#pragma unroll
+    for (int k = 0; k < kEncLdsIters; ++k) {
+      const int64_t ik = i + (int64_t)k * kEncLdsThreads * 4;
+      q[k] = ik < hi ? ld4(id, ik, n, -1) : make_int4(-1, -1, -1, -1);
+    }
+#pragma unroll
+    for (int k = 0; k < kEncLdsIters; ++k) {
+      const int64_t ik = i + (int64_t)k * kEncLdsThreads * 4;
+      const int32_t v[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (v[j] < 0 || v[j] >= bound)
+          bad |= ik < hi && ik + j < n;
+        else
+          atomicMin(&tab[v[j]], (int32_t)(ik + j));
+      }
+    }
+  }
+  if (bad) *err = 1;
+  __syncthreads();
+  for (int v = threadIdx.x; v < bound; v += kEncLdsThreads) {
+    const int32_t t = tab[v];
+    if (t != 0x7FFFFFFF && first[v] > t) atomicMin(&first[v], t);
+  }
+}
+__global__ __launch_bounds__(kEncLdsThreads) void k_enc_emit_lds(const int32_t *id, int64_t n, int bound,
+                                                                 const int32_t *rank_of, int32_t *idx) {
+  __shared__ int32_t tab[kEncLdsIds];
+  for (int v = threadIdx.x; v < bound; v += kEncLdsThreads) tab[v] = rank_of[v];
+  __syncthreads();
+  int64_t lo, hi;
+  enc_lds_range(n, lo, hi);
+  for (int64_t i = lo + (int64_t)threadIdx.x * 4; i < hi; i += (int64_t)kEncLdsThreads * 4 * kEncLdsIters) {
+    int4 q[kEncLdsIters];
+#pragma unroll
+    for (int k = 0; k < kEncLdsIters; ++k) {
+      const int64_t ik = i + (int64_t)k * kEncLdsThreads * 4;
+      q[k] = ik < hi ? ld4(id, ik, n, -1) : make_int4(-1, -1, -1, -1);
+    }
+#pragma unroll
+    for (int k = 0; k < kEncLdsIters; ++k) {
+      const int64_t ik = i + (int64_t)k * kEncLdsThreads * 4;
+      if (ik >= hi) continue;
+      const int32_t v[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+      int32_t r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = (v[j] < 0 || v[j] >= bound) ? -1 : tab[v[j]];
+      if (ik + 3 < n) {
+        *reinterpret_cast<int4 *>(idx + ik) = make_int4(r[0], r[1], r[2], r[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (ik + j < n) idx[ik + j] = r[j];
+      }
+    }
+  }
+}
+// one workgroup per CU, fewer when the column is short (a workgroup then still has a few passes of its own)
+static inline unsigned enc_lds_grid(int64_t n) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1)
+      v = 256;
+    cus = v;
+  }
+  const int64_t per = (int64_t)kEncLdsThreads * 4 * kEncLdsIters;
+  const int64_t want = (n + per - 1) / per;
+  return (unsigned)(want < 1 ? 1 : want > cus ? cus : want);
 }
 
 static inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
@@ -915,13 +1050,22 @@ int anirec_ingest_encode(const int32_t *id, int64_t n, int32_t id_bound, int32_t
   ANIREC_HIP_CHECK(hipMemsetAsync(err_flag, 0, 4, s));
   ANIREC_HIP_CHECK(hipMemsetAsync(bits, 0, nw * 4, s));
   ANIREC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)first, 0x7FFFFFFF, (size_t)id_bound, s));
-  hipLaunchKernelGGL(k_enc_first, dim3(quad_grid(n, kEncIters)), dim3(256), 0, s, id, n, id_bound, first, err_flag);
+  const bool lds = id_bound <= kEncLdsIds;  // the id tables fit a CU's LDS
+  if (lds) {
+    hipLaunchKernelGGL(k_enc_first_lds, dim3(enc_lds_grid(n)), dim3(kEncLdsThreads), 0, s, id, n, id_bound, first, err_flag);
+  } else {
+    hipLaunchKernelGGL(k_enc_first, dim3(quad_grid(n, kEncIters)), dim3(256), 0, s, id, n, id_bound, first, err_flag);
+  }
   hipLaunchKernelGGL(k_enc_bits, dim3(gb), dim3(256), 0, s, first, id_bound, bits);
   hipLaunchKernelGGL(k_bits_reduce, dim3(nb), dim3(256), 0, s, bits, bsum);
   hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, bsum, nb, n_unique);
   hipLaunchKernelGGL(k_bits_apply, dim3(nb), dim3(256), 0, s, bits, bsum, wpre);
   hipLaunchKernelGGL(k_enc_rank, dim3(gb), dim3(256), 0, s, first, id_bound, bits, wpre, out_uniques);
-  hipLaunchKernelGGL(k_enc_emit, dim3(quad_grid(n, kEncIters)), dim3(256), 0, s, id, n, id_bound, first, out_index);
+  if (lds) {
+    hipLaunchKernelGGL(k_enc_emit_lds, dim3(enc_lds_grid(n)), dim3(kEncLdsThreads), 0, s, id, n, id_bound, first, out_index);
+  } else {
+    hipLaunchKernelGGL(k_enc_emit, dim3(quad_grid(n, kEncIters)), dim3(256), 0, s, id, n, id_bound, first, out_index);
+  }
   return (int)hipGetLastError();
 }
 

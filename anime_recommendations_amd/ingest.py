@@ -61,9 +61,19 @@ def _aligned(t):
     return t if t.data_ptr() % 16 == 0 else t.clone()
 
 
+class Columns(dict):
+    """Device columns + ``bounds``: exclusive upper bounds of the id columns (the sizes of the direct-index
+    tables), known without another pass over the column."""
+
+    def __init__(self, *a, bounds=None, **kw):
+        super().__init__(*a, **kw)
+        self.bounds = dict(bounds or {})
+
+
 def preprocess_columns(cols, num_reviews, drop_unwatched=False, drop_plan=False, drop_half_watched=False):
     """drop_useless (+ drop_half_watched) + scale_ratings on device columns.
-    Returns a dict of device tensors with the surviving rows in their original order."""
+    Returns a dict of device tensors with the surviving rows in their original order; its ``bounds`` are the
+    input's id bounds (the surviving ids are a subset), so a following ``encode_columns`` need not scan for them."""
     _need_gpu()
     lib = _lib.load()
     u, a = _aligned(cols["user_id"]), _aligned(cols["anime_id"])
@@ -73,12 +83,14 @@ def preprocess_columns(cols, num_reviews, drop_unwatched=False, drop_plan=False,
     n = int(u.numel())
     dev = u.device
     if n == 0:
-        out = {k: cols[k][:0] for k in COLUMNS}
+        out = Columns({k: cols[k][:0] for k in COLUMNS})
         if drop_half_watched:
             out["max_eps"], out["half_eps"] = a[:0], r[:0]
         return out
+    known = getattr(cols, "bounds", {})
     opts = _lib.IngestOpts(int(num_reviews), int(bool(drop_unwatched)), int(bool(drop_plan)),
-                           int(bool(drop_half_watched)), _bound(u), _bound(a))
+                           int(bool(drop_half_watched)), known.get("user_id") or _bound(u),
+                           known.get("anime_id") or _bound(a))
     ou, oa = torch.empty_like(u), torch.empty_like(a)
     orr, os_, oe = torch.empty_like(r), torch.empty_like(s), torch.empty_like(e)
     n_out = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -101,15 +113,17 @@ def preprocess_columns(cols, num_reviews, drop_unwatched=False, drop_plan=False,
     if m and bool(torch.isnan(orr[0])):
         # max == min: the reference's scale_ratings raises here too (preprocess.py:115, Python floats)
         raise ZeroDivisionError("float division by zero (all surviving ratings are equal)")
-    out = {"user_id": ou[:m], "anime_id": oa[:m], "rating": orr[:m], "watching_status": os_[:m],
-           "watched_episodes": oe[:m]}
+    out = Columns({"user_id": ou[:m], "anime_id": oa[:m], "rating": orr[:m], "watching_status": os_[:m],
+                   "watched_episodes": oe[:m]},
+                  bounds={"user_id": opts.user_id_bound, "anime_id": opts.anime_id_bound})
     if half is not None:
         out["max_eps"], out["half_eps"] = half[0][:m], half[1][:m]
     return out
 
 
-def encode_ids(ids):
-    """``Series.unique()`` encoding on the GPU: (index int32 [n], uniques int32 [n_unique])."""
+def encode_ids(ids, bound=None):
+    """``Series.unique()`` encoding on the GPU: (index int32 [n], uniques int32 [n_unique]).
+    ``bound``: an exclusive upper bound of the ids if the caller knows one (default: max + 1, one pass more)."""
     _need_gpu()
     lib = _lib.load()
     ids = _aligned(ids)
@@ -118,7 +132,7 @@ def encode_ids(ids):
     dev = ids.device
     if n == 0:
         return ids.clone(), ids.clone()
-    bound = _bound(ids)
+    bound = int(bound) if bound else _bound(ids)
     idx = torch.empty_like(ids)
     uniq = torch.empty(min(n, bound), dtype=torch.int32, device=dev)
     n_u = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -166,8 +180,9 @@ def encode_columns(cols, shuffle=True, random_state=42) -> EncodedRatings:
     with ``df.sample(frac=1, random_state=42)`` (the permutation itself is NumPy's MT19937 stream,
     generated on the host; the three columns are permuted on the GPU)."""
     from . import data, ops
-    ui, user_ids = encode_ids(cols["user_id"])
-    ai, anime_ids = encode_ids(cols["anime_id"])
+    known = getattr(cols, "bounds", {})
+    ui, user_ids = encode_ids(cols["user_id"], known.get("user_id"))
+    ai, anime_ids = encode_ids(cols["anime_id"], known.get("anime_id"))
     r = cols["rating"]
     if shuffle and ui.numel():
         perm = torch.as_tensor(data.shuffle_order(int(ui.numel()), random_state), device=ui.device)

@@ -553,8 +553,8 @@ def run_ingest(cpu_baseline=True):
 
     def once():
         out = ingest.preprocess_columns(cols, num_reviews=250, drop_plan=True)
-        enc_u = ingest.encode_ids(out["user_id"])
-        enc_a = ingest.encode_ids(out["anime_id"])
+        enc_u = ingest.encode_ids(out["user_id"], out.bounds["user_id"])
+        enc_a = ingest.encode_ids(out["anime_id"], out.bounds["anime_id"])
         return out, enc_u, enc_a
     once()
     torch.cuda.synchronize()

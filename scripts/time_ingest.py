@@ -25,7 +25,8 @@ for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     out = ingest.preprocess_columns(cols, num_reviews=250, drop_plan=True)
     torch.cuda.synchronize(); t1 = time.perf_counter()
-    ui, uu = ingest.encode_ids(out["user_id"]); ai, au = ingest.encode_ids(out["anime_id"])
+    ui, uu = ingest.encode_ids(out["user_id"], out.bounds["user_id"])
+    ai, au = ingest.encode_ids(out["anime_id"], out.bounds["anime_id"])
     torch.cuda.synchronize(); t2 = time.perf_counter()
 m = out["user_id"].numel()
 print("ingest n=%d kept=%d: preprocess %.2f ms (%.2f G rows/s), encode x2 %.2f ms; users %d anime %d" %

@@ -121,6 +121,9 @@ def test_encode_matches_series_unique():
         want_idx, want_uniq = orc.encode(pd.Series(ids))
         np.testing.assert_array_equal(idx.cpu().numpy(), want_idx)
         np.testing.assert_array_equal(uniq.cpu().numpy(), want_uniq)
+        # a caller-supplied bound (any upper bound of the ids: preprocess hands its input's on) changes nothing
+        idx2, uniq2 = ingest.encode_ids(torch.as_tensor(ids, device="cuda"), bound=3 * hi + 977)
+        assert torch.equal(idx2, idx) and torch.equal(uniq2, uniq)
 
 
 def test_preprocess_then_encode_feeds_training_layout():
