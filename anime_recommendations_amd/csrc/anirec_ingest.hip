@@ -63,31 +63,51 @@ __host__ __device__ inline double ord2d(unsigned long long o) {
   memcpy(&d, &b, 8);
   return d;
 }
+// order-preserving float <-> uint32 (-0.0 below +0.0, like d2ord)
+__device__ __forceinline__ uint32_t f2ord(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return (b >> 31) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) { return __uint_as_float((o >> 31) ? (o & 0x7FFFFFFFu) : ~o); }
 // ---- the front pass -------------------------------------------------------------------------------------------
 // dropna, the two row-local filters, drop_duplicates(keep='first'), value_counts(user_id) and the num_reviews
 // filter in ONE read of the five columns.
 //
 // Identical rows share their user, so duplicates can only meet inside the rows of one user.  The table is cut into
 // chunks of kChunk consecutive rows, one workgroup each; k_ing_span first records every user's first and last row.
-// A user whose rows all lie inside one chunk is LOCAL to it: its duplicates are found in an LDS hash table of the
-// chunk, its rating count is complete when the chunk is done (counted in LDS, at the slot of the user's first
-// row), so the num_reviews filter (and min / max of the surviving ratings) is settled before the workgroup leaves.
-// The raw animelist is grouped by user, so the only non-local rows are those of the users whose block of rows
-// straddles a chunk boundary (a few % of the table): they are appended to a list and go through the global hash
-// table (k_nl_*), which is sized and cleared for the list, not for the table.  Nothing assumes the grouping: a
-// table in random order just has every row on the list.
-constexpr int kChunk = 8192;                  // rows per workgroup; two workgroups share a CU's LDS
+// A user whose first row lies in a chunk is OWNED by that chunk's workgroup if its last row lies in the chunk too or
+// in the rows the chunk's last user reaches over the boundary (the workgroup reads on to that user's last row, at
+// most kExt rows): its duplicates are found in an LDS hash table of the workgroup, its rating count is complete when
+// the workgroup is done (counted in LDS, at the slot of the user's first row), so the num_reviews filter (and min /
+// max of the surviving ratings) is settled before the workgroup leaves.  The next workgroup skips the rows its
+// neighbour owns — both decide from the same two tables, so every row has exactly one owner.  The raw animelist is
+// grouped by user: every user is owned, except one whose block is longer than the rows a workgroup may read on.
+// Rows of users nobody owns are appended to a list and go through the global hash table (k_nl_*), which is sized
+// and cleared for the list, not for the table.  Nothing assumes the grouping: a table in random order just has
+// every row on the list.
+constexpr int kChunk = 8192;                  // rows whose users a workgroup owns; two workgroups share a CU's LDS
+constexpr int kExt = 4096;                    // rows it may read on for its last user
+constexpr int kSpanRows = kChunk + kExt;
 constexpr int kFrontThreads = 512;
-constexpr int kQuads = kChunk / (4 * kFrontThreads);  // a lane owns 4 consecutive rows in each of kQuads passes
-constexpr int kLdsSlots = 2 * kChunk;         // 4-byte slots {18-bit tag | 13-bit row in chunk}: 64 KB
+constexpr int kQuads = kSpanRows / (4 * kFrontThreads);  // a lane owns 4 consecutive rows in each of kQuads passes
+constexpr int kLdsSlots = 2 * kChunk;         // 4-byte slots {17-bit tag | 14-bit row in the span}: 64 KB
 constexpr uint32_t kLdsEmpty = 0xFFFFFFFFu;   // no entry has it: the top tag bit is always 0
-constexpr uint32_t kRowMask = kChunk - 1;
-static_assert(kChunk % kScanTile == 0 && (kChunk & (kChunk - 1)) == 0, "chunk = whole scan tiles, power of two");
-static_assert(kQuads * 4 * kFrontThreads == kChunk && kChunk / kScanTile == 2 && kQuads % 2 == 0, "row mapping");
+constexpr uint32_t kRowMask = 16383;
+constexpr int kSpanTiles = kSpanRows / kScanTile;
+static_assert(kChunk % kScanTile == 0 && kExt % kScanTile == 0 && (kChunk & (kChunk - 1)) == 0, "whole scan tiles");
+static_assert(kQuads * 4 * kFrontThreads == kSpanRows && kChunk / kScanTile == 2 && kQuads % 2 == 0 &&
+                  kSpanRows <= (int)kRowMask && kQuads % kSpanTiles == 0,
+              "row mapping");
 
 __device__ __forceinline__ int4 ld4(const int32_t *p, int64_t i, int64_t n, int32_t fill) {
   if (i + 3 < n) return *reinterpret_cast<const int4 *>(p + i);
   return make_int4(i < n ? p[i] : fill, i + 1 < n ? p[i + 1] : fill, i + 2 < n ? p[i + 2] : fill, fill);
+}
+
+// the same with a 32-bit row number relative to a uniform base pointer
+__device__ __forceinline__ int4 ld4r(const int32_t *p, int r, int lim, int32_t fill) {
+  if (r + 3 < lim) return *reinterpret_cast<const int4 *>(p + r);
+  return make_int4(r < lim ? p[r] : fill, r + 1 < lim ? p[r + 1] : fill, r + 2 < lim ? p[r + 2] : fill, fill);
 }
 
 // first / last row of every user (all rows with a valid id, whatever their other columns hold).  A lane reads 4
@@ -160,9 +180,11 @@ __device__ __forceinline__ uint32_t row_hash32(const RowVals &v) {
   h = (h ^ (h >> 13)) * 0xC2B2AE3Du;
   return h ^ (h >> 16);
 }
-__device__ __forceinline__ bool row_eq(const IngestCols &c, const RowVals &v, int64_t j) {
-  return v.u == c.user[j] && v.a == c.anime[j] && v.s == c.status[j] && v.e == c.episodes[j] &&
-         rating_bits(v.r) == rating_bits(c.rating[j]);
+
+// a row in registers against a row of the span in memory (scalar column bases + a 32-bit row number)
+__device__ __forceinline__ bool row_eq_rel(const int32_t *pu, const int32_t *pa, const double *pr, const int32_t *ps,
+                                           const int32_t *pe, const RowVals &v, int j) {
+  return v.u == pu[j] && v.a == pa[j] && v.s == ps[j] && v.e == pe[j] && rating_bits(v.r) == rating_bits(pr[j]);
 }
 
 struct FrontArgs {
@@ -171,60 +193,91 @@ struct FrontArgs {
   int drop_unwatched, drop_plan, user_bound, anime_bound, num_reviews, n_tiles;
   const int32_t *ufirst, *ulast;
   uint8_t *keep;       // [chunks * kChunk]
-  int32_t *tile_cnt;   // [n_tiles] surviving rows per scan tile (the list kernels subtract what they drop later)
+  int32_t *tile_cnt;   // zeroed [n_tiles]: surviving rows per scan tile (the list kernels subtract what they drop later)
   int32_t *nl_list;    // rows of non-local users that passed the row filters
   int32_t *nl_count;   // zeroed
   unsigned long long *mm;
   int32_t *err;
 };
 
-// per-row state carried from phase A to phase C: bit 15 = passed the row filters, bit 14 = local user,
+// per-row state carried from phase A to phase C: bit 15 = passed the row filters, bit 14 = owned user,
 // bits 0..12 = the user's first row in the chunk (the slot of its counter)
 constexpr uint32_t kOk = 0x8000u, kLocal = 0x4000u;
 
+// rows the last user of the chunk that ends at row `end` reaches past it — the rows that chunk's workgroup reads on
+// (0: the chunk ends with its user, the user started before the chunk, or its block is longer than kExt).  The
+// workgroup of the chunk and its right neighbour both call this with the same `end`.
+__device__ __forceinline__ int reach_over(const FrontArgs &a, int64_t end) {
+  if (end <= 0 || end >= a.n) return 0;
+  const int32_t u = a.c.user[end - 1];
+  if (u < 0 || u >= a.user_bound) return 0;
+  const int64_t f = a.ufirst[u], l = a.ulast[u];
+  return (f >= end - kChunk && l >= end && l < end + kExt) ? (int)(l - end + 1) : 0;
+}
+
 template <bool kMinMax>
-__global__ __launch_bounds__(kFrontThreads, 2) void k_ing_front(FrontArgs a) {
+__global__ __launch_bounds__(kFrontThreads, 4) void k_ing_front(FrontArgs a) {
   __shared__ uint32_t tab[kLdsSlots];  // phase A: the hash table; afterwards [0, kChunk): the users' counters
-  __shared__ uint8_t keepl[kChunk];
-  __shared__ int32_t tile_l[2];
+  __shared__ uint8_t keepl[kSpanRows];
+  __shared__ int32_t tile_l[kSpanTiles];
   __shared__ int32_t nl_total, nl_base, nl_fill;
   __shared__ unsigned long long red[2][kFrontThreads / 64];
   const int tid = threadIdx.x, lane = lane_id();
   const IngestCols &c = a.c;
   const int64_t base = (int64_t)blockIdx.x * kChunk;
+  const int base32 = (int)base;  // n < 2^30: row numbers fit 32 bits
+  // uniform column bases + 32-bit row numbers inside the span: scalar base + one offset register per access
+  const int lim = (int)((a.n - base < 2 * kSpanRows) ? a.n - base : 2 * kSpanRows);  // rows of the table from `base` on
+  const int32_t *pu = c.user + base, *pa = c.anime + base, *ps = c.status + base, *pe = c.episodes + base;
+  const double *pr = c.rating + base;
+  uint8_t *pk = a.keep + base;
+  // the rows this workgroup reads on behind its chunk, and the rows at the chunk's front its left neighbour reads
+  const int ext = reach_over(a, base + kChunk), ext_prev = reach_over(a, base);
 
   {
     uint4 *t4 = reinterpret_cast<uint4 *>(tab);
     for (int k = tid; k < kLdsSlots / 4; k += kFrontThreads) t4[k] = make_uint4(kLdsEmpty, kLdsEmpty, kLdsEmpty, kLdsEmpty);
     uint4 *k4 = reinterpret_cast<uint4 *>(keepl);
-    for (int k = tid; k < kChunk / 16; k += kFrontThreads) k4[k] = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
-    if (tid < 2) tile_l[tid] = 0;
+    for (int k = tid; k < kSpanRows / 16; k += kFrontThreads) k4[k] = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+    if (tid < kSpanTiles) tile_l[tid] = 0;
     if (tid == 0) nl_total = 0, nl_fill = 0;
   }
   __syncthreads();
 
-  // phase A: row filters; rows of local users into the LDS table, the later members of a class lose their flag
-  uint16_t meta[kQuads][4];
-  double rat[kMinMax ? kQuads : 1][4];
+  // phase A: row filters; rows of owned users into the LDS table, the later members of a class lose their flag
+  // per row one word: the low half is the state above; the high half the row's rating for the min / max of phase C,
+  // as the upper 16 bits of the order-preserving key of its float value — ratings are small integers in practice; a
+  // rating that is not such a float is flagged and read again
+  uint32_t mk[kQuads][4], inexact = 0, mine = 0;  // mine: 4 bits per quad, the row's flag is this workgroup's to write
   bool bad = false;
 #pragma unroll
   for (int h = 0; h < kQuads; h += 2) {  // two quads of loads in flight
+    if (h * kFrontThreads * 4 >= kChunk && (h * kFrontThreads + (tid & ~63)) * 4 >= kChunk + ext) {
+      // a wave whose rows all lie behind the last row this workgroup reads (most waves, behind the chunk itself)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mk[h][j] = mk[h + 1][j] = 0;
+      continue;
+    }
     int4 U[2], A[2], S[2], E[2];
     double R[2][4];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const int64_t i = base + ((h + b) * kFrontThreads + tid) * 4;
-      U[b] = ld4(c.user, i, a.n, ANIREC_NULL_I32);
-      A[b] = ld4(c.anime, i, a.n, 0);
-      S[b] = ld4(c.status, i, a.n, 0);
-      E[b] = ld4(c.episodes, i, a.n, 0);
-      if (i + 3 < a.n) {
-        const double2 r0 = *reinterpret_cast<const double2 *>(c.rating + i);
-        const double2 r1 = *reinterpret_cast<const double2 *>(c.rating + i + 2);
-        R[b][0] = r0.x, R[b][1] = r0.y, R[b][2] = r1.x, R[b][3] = r1.y;
+      const int r0 = ((h + b) * kFrontThreads + tid) * 4;
+      U[b] = make_int4(ANIREC_NULL_I32, ANIREC_NULL_I32, ANIREC_NULL_I32, ANIREC_NULL_I32);
+      A[b] = S[b] = E[b] = make_int4(0, 0, 0, 0);
+      R[b][0] = R[b][1] = R[b][2] = R[b][3] = 0.0;
+      if (r0 >= kChunk + ext) continue;  // behind the last row this workgroup reads
+      U[b] = ld4r(pu, r0, lim, ANIREC_NULL_I32);
+      A[b] = ld4r(pa, r0, lim, 0);
+      S[b] = ld4r(ps, r0, lim, 0);
+      E[b] = ld4r(pe, r0, lim, 0);
+      if (r0 + 3 < lim) {
+        const double2 r0v = *reinterpret_cast<const double2 *>(pr + r0);
+        const double2 r1v = *reinterpret_cast<const double2 *>(pr + r0 + 2);
+        R[b][0] = r0v.x, R[b][1] = r0v.y, R[b][2] = r1v.x, R[b][3] = r1v.y;
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) R[b][j] = i + j < a.n ? c.rating[i + j] : 0.0;
+        for (int j = 0; j < 4; ++j) R[b][j] = r0 + j < lim ? pr[r0 + j] : 0.0;
       }
     }
     int32_t F[2][4], L[2][4];
@@ -244,8 +297,9 @@ __global__ __launch_bounds__(kFrontThreads, 2) void k_ing_front(FrontArgs a) {
         if (o && a.drop_unwatched && ep[j] == 0) o = false;
         if (o && a.drop_plan && st[j] == 6) o = false;
         ok[b][j] = o;
-        F[b][j] = a.ufirst[o ? u[j] : 0];
-        L[b][j] = a.ulast[o ? u[j] : 0];
+        const bool uv = u[j] >= 0 && u[j] < a.user_bound;  // the ownership of a row is its user's, kept or not
+        F[b][j] = uv ? a.ufirst[u[j]] - base32 : -0x40000000;  // relative to the chunk's first row
+        L[b][j] = uv ? a.ulast[u[j]] - base32 : -0x40000000;
       }
     }
 #pragma unroll
@@ -255,20 +309,37 @@ __global__ __launch_bounds__(kFrontThreads, 2) void k_ing_front(FrontArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int ridx = ((h + b) * kFrontThreads + tid) * 4 + j;
-        if (kMinMax) rat[h + b][j] = R[b][j];
-        meta[h + b][j] = 0;
-        if (!ok[b][j]) continue;
-        meta[h + b][j] = kOk;
-        if ((int64_t)F[b][j] < base || (int64_t)L[b][j] >= base + kChunk) continue;  // non-local: the list
-        meta[h + b][j] = (uint16_t)(kOk | kLocal | (uint32_t)(F[b][j] - base));
+        const int32_t f = F[b][j], l = L[b][j];
+        // the user starts in this chunk and ends inside the rows this workgroup reads / the same for the left
+        // neighbour (a row without a valid user id belongs to the chunk it lies in)
+        const bool own = (uint32_t)f < (uint32_t)kChunk && l < kChunk + ext;
+        const bool prev_owns = (uint32_t)(f + kChunk) < (uint32_t)kChunk && l < ext_prev;
+        const bool my = ridx < kChunk ? !prev_owns : (ridx < kChunk + ext && own);
+        if (my) mine |= 1u << ((h + b) * 4 + j);
+        mk[h + b][j] = 0;
+        if (kMinMax) {
+          // the double's bits: exact as a float with 7 mantissa bits iff the 45 lower mantissa bits are zero and the
+          // exponent is a normal float's (or the value is a zero); the float's upper half follows from the bits
+          const uint64_t db = (uint64_t)__double_as_longlong(R[b][j]);
+          const uint32_t dh = (uint32_t)(db >> 32), ex = (dh >> 20) & 0x7FFu;
+          const bool zero = (db << 1) == 0;
+          const bool exact = ((uint32_t)db == 0) & ((dh & 0x1FFFu) == 0) & ((ex - 897u < 254u) | zero);
+          const uint32_t fh = zero ? (dh >> 16 & 0x8000u) : ((dh >> 16 & 0x8000u) | ((ex - 896u) << 7) | ((dh >> 13) & 0x7Fu));
+          if (!exact) inexact |= 1u << ((h + b) * 4 + j);
+          mk[h + b][j] = f2ord(__uint_as_float(fh << 16)) & 0xFFFF0000u;
+        }
+        if (!my || !ok[b][j]) continue;
+        mk[h + b][j] |= kOk;
+        if (!own) continue;  // nobody's: the list
+        mk[h + b][j] |= kLocal | (uint32_t)f;
         const RowVals v{u[j], an[j], st[j], ep[j], R[b][j]};
         const uint32_t hh = row_hash32(v);
-        const uint32_t entry = (hh & 0x7FFFE000u) | (uint32_t)ridx;
+        const uint32_t entry = (hh & 0x7FFFC000u) | (uint32_t)ridx;
         uint32_t s = hh & (kLdsSlots - 1);
         for (;;) {
           const uint32_t old = atomicCAS(&tab[s], kLdsEmpty, entry);
           if (old == kLdsEmpty) break;
-          if (((old ^ entry) & ~kRowMask) == 0 && row_eq(c, v, base + (old & kRowMask))) {
+          if (((old ^ entry) & ~kRowMask) == 0 && row_eq_rel(pu, pa, pr, ps, pe, v, (int)(old & kRowMask))) {
             // same tag: the minimum entry is the minimum row; prev is a member of the same class (see k_nl_insert)
             const uint32_t prev = atomicMin(&tab[s], entry);
             keepl[prev > entry ? (prev & kRowMask) : (uint32_t)ridx] = 0;
@@ -284,9 +355,9 @@ __global__ __launch_bounds__(kFrontThreads, 2) void k_ing_front(FrontArgs a) {
   for (int k = tid; k < kChunk / 4; k += kFrontThreads) reinterpret_cast<uint4 *>(tab)[k] = make_uint4(0, 0, 0, 0);
   __syncthreads();
 
-  // phase B: value_counts of the local users over the rows that are left, one LDS atomic per run of equal users
-  // among a lane's 4 consecutive rows.  Every row of a local user is in this chunk: after the barrier the counts
-  // are final.
+  // phase B: value_counts of the owned users over the rows that are left, one LDS atomic per run of equal users
+  // among a lane's 4 consecutive rows.  Every row of an owned user is one of this workgroup's: after the barrier
+  // the counts are final.
   int nl = 0;
 #pragma unroll
   for (int q = 0; q < kQuads; ++q) {
@@ -294,15 +365,15 @@ __global__ __launch_bounds__(kFrontThreads, 2) void k_ing_front(FrontArgs a) {
     int run = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      uint32_t m = meta[q][j];
+      uint32_t m = mk[q][j] & 0xFFFFu;
       if (!((kb >> (8 * j)) & 1u)) m = 0;  // lost to an earlier equal row
-      meta[q][j] = (uint16_t)m;
+      mk[q][j] = (mk[q][j] & 0xFFFF0000u) | m;
       nl += (m & (kOk | kLocal)) == kOk;
       const bool cnt = (m & kLocal) != 0;
-      const bool same_next = j < 3 && cnt && ((kb >> (8 * (j + 1))) & 1u) && meta[q][j + 1] == m;
+      const bool same_next = j < 3 && cnt && ((kb >> (8 * (j + 1))) & 1u) && (mk[q][(j + 1) & 3] & 0xFFFFu) == m;
       run += cnt;
       if (cnt && !same_next) {
-        atomicAdd(&tab[m & kRowMask], (uint32_t)run);
+        atomicAdd(&tab[m & (kChunk - 1)], (uint32_t)run);
         run = 0;
       }
     }
@@ -314,23 +385,29 @@ __global__ __launch_bounds__(kFrontThreads, 2) void k_ing_front(FrontArgs a) {
   if (tid == 0 && nl_total) nl_base = atomicAdd(a.nl_count, nl_total);
   __syncthreads();
 
-  // phase C: the num_reviews filter for the local rows, the flags, the list of non-local rows
+  // phase C: the num_reviews filter for the owned rows, the flags, the list of nobody's rows
   unsigned long long lo = ~0ULL, hi = 0ULL;
-  int tcnt[2] = {0, 0};
+  int tcnt[kSpanTiles];
+#pragma unroll
+  for (int t = 0; t < kSpanTiles; ++t) tcnt[t] = 0;
 #pragma unroll
   for (int q = 0; q < kQuads; ++q) {
-    const int64_t i = base + (q * kFrontThreads + tid) * 4;
+    const int r0 = (q * kFrontThreads + tid) * 4;
+    const uint32_t mq = (mine >> (q * 4)) & 0xFu;
     uint32_t kb = 0;
     int nlq = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const uint32_t m = meta[q][j];
+      const uint32_t m = mk[q][j] & 0xFFFFu;
       bool kept = (m & kOk) != 0;
       if (m & kLocal) {
-        if ((int32_t)tab[m & kRowMask] < a.num_reviews) {
+        if ((int32_t)tab[m & (kChunk - 1)] < a.num_reviews) {
           kept = false;
         } else if (kMinMax) {
-          const unsigned long long o = d2ord(rat[q][j]);
+          // the key's lower half: zeros of a non-negative float, ones of a negative one (f2ord flips those)
+          const uint32_t kh = mk[q][j] & 0xFFFF0000u, key = kh | ((kh >> 31) ? 0u : 0xFFFFu);
+          const unsigned long long o =
+              ((inexact >> (q * 4 + j)) & 1u) ? d2ord(pr[r0 + j]) : d2ord((double)ord2f(key));
           lo = o < lo ? o : lo;
           hi = o > hi ? o : hi;
         }
@@ -338,10 +415,16 @@ __global__ __launch_bounds__(kFrontThreads, 2) void k_ing_front(FrontArgs a) {
         nlq += kept;
       }
       kb |= (uint32_t)kept << (8 * j);
-      tcnt[q / (kQuads / 2)] += kept;
+      tcnt[q / (kQuads / kSpanTiles)] += kept;
     }
-    *reinterpret_cast<uint32_t *>(&a.keep[i]) = kb;
-    if (__ballot(nlq != 0)) {  // rare: the rows of a user that straddles the chunk boundary
+    if (mq == 0xFu) {
+      *reinterpret_cast<uint32_t *>(pk + r0) = kb;
+    } else {  // a quad on the border between this workgroup's rows and a neighbour's
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if ((mq >> j) & 1u) pk[r0 + j] = (uint8_t)((kb >> (8 * j)) & 1u);
+    }
+    if (__ballot(nlq != 0)) {  // rare: the rows of a user nobody owns
       int incl = nlq;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
@@ -353,11 +436,11 @@ __global__ __launch_bounds__(kFrontThreads, 2) void k_ing_front(FrontArgs a) {
       off = __shfl(off, 63, 64) + nl_base + incl - nlq;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if ((meta[q][j] & (kOk | kLocal)) == kOk) a.nl_list[off++] = (int32_t)(i + j);
+        if ((mk[q][j] & (kOk | kLocal)) == kOk) a.nl_list[off++] = base32 + r0 + j;
     }
   }
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < kSpanTiles; ++t) {
     int v = tcnt[t];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -376,10 +459,9 @@ __global__ __launch_bounds__(kFrontThreads, 2) void k_ing_front(FrontArgs a) {
     }
   }
   __syncthreads();
-  if (tid < 2) {
-    const int t = blockIdx.x * 2 + tid;
-    if (t < a.n_tiles) a.tile_cnt[t] = tile_l[tid];
-  }
+  // the tiles of the chunk, and the tile behind it that the rows read on lie in (zeroed by the host: two
+  // workgroups add to it)
+  if (tid < kSpanTiles && tile_l[tid]) atomicAdd(&a.tile_cnt[blockIdx.x * (kChunk / kScanTile) + tid], tile_l[tid]);
   if (kMinMax && tid == 0) {  // one pair of atomics per workgroup
     for (int w = 1; w < kFrontThreads / 64; ++w) {
       lo = red[0][w] < lo ? red[0][w] : lo;
@@ -970,6 +1052,7 @@ int anirec_ingest_preprocess(const int32_t *user_id, const int32_t *anime_id, co
   ANIREC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)w.ulast, -1, ub, s));
   ANIREC_HIP_CHECK(hipMemsetAsync(w.mm, 0xFF, 8, s));
   ANIREC_HIP_CHECK(hipMemsetAsync(w.mm + 1, 0, 16, s));  // max, list length
+  ANIREC_HIP_CHECK(hipMemsetAsync(w.bsum, 0, (size_t)n_tiles * 4, s));
   hipLaunchKernelGGL(k_ing_span, dim3(quad_grid(n, kSpanIters)), dim3(256), 0, s, user_id, n, opts->user_id_bound,
                      w.ufirst, w.ulast);
   const FrontArgs fa{c,        n,        opts->drop_unwatched, opts->drop_plan, opts->user_id_bound, opts->anime_id_bound,
