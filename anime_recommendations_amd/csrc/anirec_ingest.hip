@@ -170,17 +170,15 @@ struct RowVals {
   int32_t u, a, s, e;
   double r;
 };
-// 32 bits for the chunk's LDS table (slot = the low bits, tag = bits 13..30).  Three 32-bit multiplies: the
-// 64-bit mixer of the list path is six 64-bit multiplies per row — a quarter of the front pass's issue time on a part whose
+// 32 bits for the chunk's LDS table (slot = the low bits, tag = bits 14..30).  Two 32-bit multiplies: the 64-bit
+// mixer of the list path is six 64-bit multiplies per row — a quarter of the front pass's issue time on a part whose
 // integer multiplier runs at quarter rate.  Rows that meet here share their user; the anime id carries the spread.
 __device__ __forceinline__ uint32_t row_hash32(const RowVals &v) {
   const uint64_t rb = rating_bits(v.r);
-  uint32_t h = ((uint32_t)v.a * 0x9E3779B1u) ^ (uint32_t)v.u;
-  h = ((h ^ (h >> 15)) * 0x85EBCA77u) ^ (uint32_t)v.e ^ ((uint32_t)v.s << 24) ^ (uint32_t)rb ^ (uint32_t)(rb >> 32);
-  h = (h ^ (h >> 13)) * 0xC2B2AE3Du;
-  return h ^ (h >> 16);
+  uint32_t h = (uint32_t)v.a * 0x9E3779B1u + (uint32_t)v.e;
+  h = ((h ^ (h >> 15)) * 0x85EBCA77u) ^ (uint32_t)v.u ^ ((uint32_t)v.s << 24) ^ (uint32_t)rb ^ (uint32_t)(rb >> 32);
+  return h ^ (h >> 13) ^ (h >> 21);
 }
-
 // a row in registers against a row of the span in memory (scalar column bases + a 32-bit row number)
 __device__ __forceinline__ bool row_eq_rel(const int32_t *pu, const int32_t *pa, const double *pr, const int32_t *ps,
                                            const int32_t *pe, const RowVals &v, int j) {
@@ -387,6 +385,7 @@ __global__ __launch_bounds__(kFrontThreads, 4) void k_ing_front(FrontArgs a) {
 
   // phase C: the num_reviews filter for the owned rows, the flags, the list of nobody's rows
   unsigned long long lo = ~0ULL, hi = 0ULL;
+  uint32_t klo = 0xFFFFu, khi = 0u;
   int tcnt[kSpanTiles];
 #pragma unroll
   for (int t = 0; t < kSpanTiles; ++t) tcnt[t] = 0;
@@ -404,12 +403,14 @@ __global__ __launch_bounds__(kFrontThreads, 4) void k_ing_front(FrontArgs a) {
         if ((int32_t)tab[m & (kChunk - 1)] < a.num_reviews) {
           kept = false;
         } else if (kMinMax) {
-          // the key's lower half: zeros of a non-negative float, ones of a negative one (f2ord flips those)
-          const uint32_t kh = mk[q][j] & 0xFFFF0000u, key = kh | ((kh >> 31) ? 0u : 0xFFFFu);
-          const unsigned long long o =
-              ((inexact >> (q * 4 + j)) & 1u) ? d2ord(pr[r0 + j]) : d2ord((double)ord2f(key));
-          lo = o < lo ? o : lo;
-          hi = o > hi ? o : hi;
+          if ((inexact >> (q * 4 + j)) & 1u) {  // not a small float: the rating again, as a double
+            const unsigned long long o = d2ord(pr[r0 + j]);
+            lo = o < lo ? o : lo;
+            hi = o > hi ? o : hi;
+          } else {  // the order of the keys is the order of the ratings
+            klo = min(klo, mk[q][j] >> 16);
+            khi = max(khi, mk[q][j] >> 16);
+          }
         }
       } else {
         nlq += kept;
@@ -447,6 +448,14 @@ __global__ __launch_bounds__(kFrontThreads, 4) void k_ing_front(FrontArgs a) {
     if (lane == 0 && v) atomicAdd(&tile_l[t], v);
   }
   if (kMinMax) {
+    if (klo <= khi) {
+      // a key's lower half: zeros of a non-negative float, ones of a negative one (f2ord flips those)
+      const uint32_t kl = klo << 16, kh = khi << 16;
+      const unsigned long long l2 = d2ord((double)ord2f(kl | ((kl >> 31) ? 0u : 0xFFFFu)));
+      const unsigned long long h2 = d2ord((double)ord2f(kh | ((kh >> 31) ? 0u : 0xFFFFu)));
+      lo = l2 < lo ? l2 : lo;
+      hi = h2 > hi ? h2 : hi;
+    }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
       const unsigned long long l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);

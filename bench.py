@@ -570,15 +570,20 @@ def run_ingest(cpu_baseline=True):
     rec = {"value": n / dt, "unit": "rows/s", "ms": dt * 1e3, "rows_in": n, "rows_out": m,
            "n_users": int(enc_u[1].numel()), "n_anime": int(enc_a[1].numel()),
            "roofline": {"kernel": "ingest pipeline (22 launches; k_ing_front — row filters, LDS dedupe and per-user "
-                                  "counts of an 8 192-row chunk — and k_ing_compact are 2/3 of it)",
+                                  "counts of an 8 192-row chunk and the rows its last user reaches past it — and "
+                                  "k_ing_compact are 3/4 of it)",
                         "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes,
+                        "limiter": "k_ing_front is bound by instruction issue (PMC, profiles/r04_pmc_ingest_front.txt: "
+                                   "3 066 vector + 2 957 scalar instructions per wave, the four waves of a SIMD "
+                                   "together in execution 106 % of the time), not by HBM",
                         "traffic": pmc_traffic("ingest", {"k_ing_span": 1, "k_ing_front<true>": 1, "k_nl_clear": 1,
                                                           "k_nl_insert": 1, "k_nl_count": 1, "k_nl_filter<true>": 1,
                                                           "k_scan_spine": 3, "k_ing_compact": 1,
-                                                          "k_enc_first": 2, "k_enc_bits": 2, "k_bits_reduce": 2,
-                                                          "k_bits_apply": 2, "k_enc_rank": 2, "k_enc_emit": 2},
-                                             source="anirec_ingest.hip")}}
+                                                          "k_enc_first": 1, "k_enc_first_lds": 1, "k_enc_bits": 2,
+                                                          "k_bits_reduce": 2, "k_bits_apply": 2, "k_enc_rank": 2,
+                                                          "k_enc_emit": 1, "k_enc_emit_lds": 1},
+                                             source=["anirec_ingest.hip", "ingest.py"])}}
     if cpu_baseline:
         import pandas as pd
         from oracle import ingest_oracle
