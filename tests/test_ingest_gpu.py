@@ -230,3 +230,60 @@ def test_preprocess_one_row_repeated_thousands_of_times():
         df = pd.concat(parts, ignore_index=True)
         want = _check(df, 10)
         assert len(want) <= len(base)
+
+
+def _blocks_frame(lengths, seed, n_anime=400, dups=0.02):
+    """One block of rows per user with the given lengths, in order; duplicates inside their user's block."""
+    rng = np.random.default_rng(seed)
+    users = np.repeat(np.arange(len(lengths)) * 7 + 3, lengths)
+    n = len(users)
+    df = pd.DataFrame({"user_id": users, "anime_id": rng.integers(1, n_anime, n), "rating": rng.integers(0, 11, n),
+                       "watching_status": rng.choice([1, 2, 3, 4, 6], n), "watched_episodes": rng.integers(0, 30, n)})
+    start = np.repeat(np.cumsum(lengths) - lengths, lengths)
+    src = rng.integers(0, n, int(n * dups))
+    dst = np.minimum(src + rng.integers(1, 200, len(src)), start[src] + np.repeat(lengths, lengths)[src] - 1)
+    df.iloc[dst] = df.iloc[src].to_numpy()          # still the same user: dst stays inside src's block
+    return df
+
+
+@pytest.mark.parametrize("reach", [0, 1, 4095, 4096, 4097, 9000])
+def test_preprocess_user_blocks_around_a_chunk_boundary(reach):
+    """k_ing_front: the workgroup of the chunk a user starts in reads on to the user's last row, at most 4 096 rows
+    past its 8 192-row chunk.  A block that ends exactly at the boundary, one row / 4 095 rows past it (owned),
+    4 096 and more (nobody's: the list), and a block over three chunks — with duplicates whose first occurrence lies on
+    the other side of the boundary, and thresholds on both sides of every block's count."""
+    lengths = [5000, 3192 - 700, 700 + reach, 300, 8192 * 2 + 11, 250, 6000]
+    assert sum(lengths[:2]) + 700 == 8192           # the third block starts 700 rows before the first boundary
+    df = _blocks_frame(lengths, seed=50 + reach)
+    for num_reviews in (1, 280, 650, 5100):
+        want = _check(df, num_reviews, drop_plan=True)
+    assert len(want) > 0
+
+
+def test_preprocess_rows_of_another_user_inside_a_block():
+    """Almost grouped: single rows of user A inside the blocks of other users, near and across chunk boundaries (the
+    bench table's duplicates do this).  A is then owned only if its first and last row allow it; whatever the
+    workgroups decide, pandas' answer must come out."""
+    lengths = [3000, 5000, 400, 7900, 300, 8100, 2000]
+    df = _blocks_frame(lengths, seed=77)
+    rng = np.random.default_rng(78)
+    n = len(df)
+    for pos in (8190, 8191, 8192, 8193, 8192 + 390, 16383, 16384, 16385, n - 1, 10, 12000):
+        src = int(rng.integers(0, n))
+        df.iloc[pos] = df.iloc[src].to_numpy()     # user, anime, ... of a row far away
+    for num_reviews in (1, 350, 4000):
+        _check(df, num_reviews)
+    _check(df, 300, drop_unwatched=True, drop_half_watched=True)
+
+
+def test_encode_id_space_at_the_lds_table_limit():
+    """k_enc_*_lds holds the id tables of up to 32 768 ids in LDS; one id more takes the global-table kernels."""
+    from anime_recommendations_amd import ingest
+    rng = np.random.default_rng(5)
+    for bound in (32767, 32768, 32769):
+        ids = rng.integers(0, bound, 200_003).astype(np.int32)
+        ids[-1] = bound - 1
+        idx, uniq = ingest.encode_ids(torch.as_tensor(ids, device="cuda"))
+        want_idx, want_uniq = orc.encode(pd.Series(ids))
+        np.testing.assert_array_equal(idx.cpu().numpy(), want_idx)
+        np.testing.assert_array_equal(uniq.cpu().numpy(), want_uniq)
