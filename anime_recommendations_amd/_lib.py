@@ -143,6 +143,7 @@ PROTOTYPES = {
     "anirec_fav_workspace_bytes": (_sz, [_i64, _i32]),
     "anirec_user_favourites": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, C.c_double, _vp, _vp, _vp, _vp, _sz, _vp]),
     "anirec_user_recs": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "anirec_ingest_id_max": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "anirec_ingest_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "anirec_ingest_preprocess": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(IngestOpts), _vp, _vp, _vp,
                                            _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -966,6 +966,40 @@ static inline unsigned enc_lds_grid(int64_t n) {
   return (unsigned)(want < 1 ? 1 : want > cus ? cus : want);
 }
 
+// max of the two id columns in one pass (the sizes of the direct-index tables; a NULL is the smallest int).  Four
+// quads of each column in flight per lane; one pair of atomics per workgroup (thousands of waves on two addresses
+// serialise in the L2).
+__global__ __launch_bounds__(256) void k_ing_id_max(const int32_t *user, const int32_t *anime, int64_t n, int32_t *out2) {
+  __shared__ int32_t red[2][4];
+  int32_t mu = ANIREC_NULL_I32, ma = ANIREC_NULL_I32;
+  const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += 4 * stride) {
+    int4 u[4], a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t ik = i + k * stride;
+      u[k] = ik < n ? ld4(user, ik, n, ANIREC_NULL_I32) : make_int4(ANIREC_NULL_I32, ANIREC_NULL_I32, ANIREC_NULL_I32, ANIREC_NULL_I32);
+      a[k] = ik < n ? ld4(anime, ik, n, ANIREC_NULL_I32) : make_int4(ANIREC_NULL_I32, ANIREC_NULL_I32, ANIREC_NULL_I32, ANIREC_NULL_I32);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      mu = max(mu, max(max(u[k].x, u[k].y), max(u[k].z, u[k].w)));
+      ma = max(ma, max(max(a[k].x, a[k].y), max(a[k].z, a[k].w)));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    mu = max(mu, __shfl_xor(mu, o, 64));
+    ma = max(ma, __shfl_xor(ma, o, 64));
+  }
+  if (lane_id() == 0) red[0][threadIdx.x >> 6] = mu, red[1][threadIdx.x >> 6] = ma;
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const int32_t *r = red[threadIdx.x];
+    atomicMax(&out2[threadIdx.x], max(max(r[0], r[1]), max(r[2], r[3])));
+  }
+}
+
 static inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 static inline size_t pad_tile(int64_t n) { return ((size_t)n + kChunk - 1) / kChunk * kChunk; }  // whole chunks
 static inline uint32_t table_slots(int64_t n) {
@@ -1025,6 +1059,16 @@ static IngestWs carve_ingest(void *workspace, int64_t n, int32_t user_bound, int
   p += 256;
   w.bytes = (size_t)(p - (char *)workspace);
   return w;
+}
+
+int anirec_ingest_id_max(const int32_t *user_id, const int32_t *anime_id, int64_t n, int32_t *out_max2, void *stream) {
+  if (!user_id || !anime_id || !out_max2 || n < 1 || n >= ((int64_t)1 << 30)) return ANIREC_EINVAL;
+  if (!aligned16(user_id) || !aligned16(anime_id)) return ANIREC_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ANIREC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)out_max2, (int)0x80000000, 2, s));
+  const int64_t want = (n + 4095) / 4096;
+  hipLaunchKernelGGL(k_ing_id_max, dim3((unsigned)(want > 2048 ? 2048 : want)), dim3(256), 0, s, user_id, anime_id, n, out_max2);
+  return (int)hipGetLastError();
 }
 
 size_t anirec_ingest_workspace_bytes(int64_t n, int32_t user_id_bound, int32_t anime_id_bound) {

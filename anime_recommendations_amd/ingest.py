@@ -28,10 +28,19 @@ def _need_gpu():
         raise _lib.AnirecError("no GPU: the anime_recommendations_amd ingest path needs an MI355X")
 
 
+class Columns(dict):
+    """Device columns + ``bounds``: exclusive upper bounds of the id columns (the sizes of the direct-index
+    tables), known without another pass over the column."""
+
+    def __init__(self, *a, bounds=None, **kw):
+        super().__init__(*a, **kw)
+        self.bounds = dict(bounds or {})
+
+
 def frame_to_columns(df, device="cuda:0"):
     """DataFrame (reference schema) -> dict of device tensors.  Integer columns become int32 with
     missing values (pandas NaN) as NULL_I32; ``rating`` becomes float64 with NaN for missing."""
-    out = {}
+    out, bounds = {}, {}
     for name in COLUMNS:
         col = df[name].to_numpy()
         if name == "rating":
@@ -47,7 +56,10 @@ def frame_to_columns(df, device="cuda:0"):
             if ints.size and (ints.max() >= 2 ** 31 or ints.min() <= NULL_I32):
                 raise ValueError("column %s does not fit int32" % name)
         out[name] = torch.as_tensor(ints.astype(np.int32), device=device)
-    return out
+        if name in ("user_id", "anime_id"):      # the id bounds while the column is still on the host
+            valid = ints[ints != NULL_I32]
+            bounds[name] = max(int(valid.max()) + 1, 1) if valid.size else 1
+    return Columns(out, bounds=bounds)
 
 
 def _bound(t):
@@ -59,15 +71,6 @@ def _aligned(t):
     """Contiguous and 16-byte aligned (the kernels read four rows per lane): a sliced view is copied."""
     t = t.contiguous()
     return t if t.data_ptr() % 16 == 0 else t.clone()
-
-
-class Columns(dict):
-    """Device columns + ``bounds``: exclusive upper bounds of the id columns (the sizes of the direct-index
-    tables), known without another pass over the column."""
-
-    def __init__(self, *a, bounds=None, **kw):
-        super().__init__(*a, **kw)
-        self.bounds = dict(bounds or {})
 
 
 def preprocess_columns(cols, num_reviews, drop_unwatched=False, drop_plan=False, drop_half_watched=False):
@@ -88,13 +91,18 @@ def preprocess_columns(cols, num_reviews, drop_unwatched=False, drop_plan=False,
             out["max_eps"], out["half_eps"] = a[:0], r[:0]
         return out
     known = getattr(cols, "bounds", {})
+    ub, ab = known.get("user_id"), known.get("anime_id")
+    if not (ub and ab):          # both maxima in one pass and one readback
+        mx = torch.empty(2, dtype=torch.int32, device=dev)
+        _lib.check(lib.anirec_ingest_id_max(_lib.ptr(u), _lib.ptr(a), n, _lib.ptr(mx), _stream()), "anirec_ingest_id_max")
+        mu, ma = mx.tolist()
+        ub, ab = ub or max(mu + 1, 1), ab or max(ma + 1, 1)
     opts = _lib.IngestOpts(int(num_reviews), int(bool(drop_unwatched)), int(bool(drop_plan)),
-                           int(bool(drop_half_watched)), known.get("user_id") or _bound(u),
-                           known.get("anime_id") or _bound(a))
+                           int(bool(drop_half_watched)), int(ub), int(ab))
     ou, oa = torch.empty_like(u), torch.empty_like(a)
     orr, os_, oe = torch.empty_like(r), torch.empty_like(s), torch.empty_like(e)
-    n_out = torch.zeros(1, dtype=torch.int64, device=dev)
-    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    res = torch.zeros(2, dtype=torch.int64, device=dev)   # row count | error flag: one readback
+    n_out, err = res[0:1], res[1:2].view(torch.int32)[0:1]
     ws = torch.empty(int(lib.anirec_ingest_workspace_bytes(n, opts.user_id_bound, opts.anime_id_bound)),
                      dtype=torch.uint8, device=dev)
     _lib.check(lib.anirec_ingest_preprocess(_lib.ptr(u), _lib.ptr(a), _lib.ptr(r), _lib.ptr(s), _lib.ptr(e), n,
@@ -107,10 +115,10 @@ def preprocess_columns(cols, num_reviews, drop_unwatched=False, drop_plan=False,
         _lib.check(lib.anirec_ingest_half_columns(_lib.ptr(oa), _lib.ptr(n_out), n, C.byref(opts), _lib.ptr(half[0]),
                                                   _lib.ptr(half[1]), _lib.ptr(ws), ws.numel(), _stream()),
                    "anirec_ingest_half_columns")
-    m = int(n_out.item())
-    if int(err.item()):
+    m, bad, first_nan = torch.cat([n_out, err.to(torch.int64), torch.isnan(orr[:1]).to(torch.int64)]).tolist()
+    if bad:
         raise ValueError("negative user_id / anime_id in the rating table")
-    if m and bool(torch.isnan(orr[0])):
+    if m and first_nan:
         # max == min: the reference's scale_ratings raises here too (preprocess.py:115, Python floats)
         raise ZeroDivisionError("float division by zero (all surviving ratings are equal)")
     out = Columns({"user_id": ou[:m], "anime_id": oa[:m], "rating": orr[:m], "watching_status": os_[:m],
@@ -135,15 +143,16 @@ def encode_ids(ids, bound=None):
     bound = int(bound) if bound else _bound(ids)
     idx = torch.empty_like(ids)
     uniq = torch.empty(min(n, bound), dtype=torch.int32, device=dev)
-    n_u = torch.zeros(1, dtype=torch.int64, device=dev)
-    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    res = torch.zeros(2, dtype=torch.int64, device=dev)   # number of ids | error flag: one readback
+    n_u, err = res[0:1], res[1:2].view(torch.int32)[0:1]
     ws = torch.empty(int(lib.anirec_ingest_encode_workspace_bytes(n, bound)), dtype=torch.uint8, device=dev)
     _lib.check(lib.anirec_ingest_encode(_lib.ptr(ids), n, bound, _lib.ptr(idx), _lib.ptr(uniq), _lib.ptr(n_u),
                                         _lib.ptr(err), _lib.ptr(ws), ws.numel(), _stream()),
                "anirec_ingest_encode")
-    if int(err.item()):
+    count, bad = res.tolist()
+    if bad & 0xFFFFFFFF:
         raise ValueError("negative id in the column to encode")
-    return idx, uniq[:int(n_u.item())]
+    return idx, uniq[:count]
 
 
 @dataclass

@@ -432,6 +432,10 @@ typedef struct anirec_ingest_opts {
  * dropped).  1 <= n < 2^30.  The five input columns and the workspace must be 16-byte aligned
  * (ANIREC_EINVAL otherwise: the kernels read four rows per lane).  Any row order is accepted; a table
  * grouped by user (the raw animelist) finds its duplicate rows in LDS, chunk by chunk. */
+/* Largest user_id and anime_id of the two columns (ANIREC_NULL_I32 if a column holds nothing else) in one pass:
+ * out_max2[0] + 1 / out_max2[1] + 1 are the id bounds anirec_ingest_opts asks for.  Device pointers, 16-byte aligned
+ * columns, stream-ordered. */
+int anirec_ingest_id_max(const int32_t *user_id, const int32_t *anime_id, int64_t n, int32_t *out_max2, void *stream);
 size_t anirec_ingest_workspace_bytes(int64_t n, int32_t user_id_bound, int32_t anime_id_bound);
 int anirec_ingest_preprocess(const int32_t *user_id, const int32_t *anime_id, const double *rating,
                              const int32_t *watching_status, const int32_t *watched_episodes, int64_t n,
