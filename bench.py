@@ -104,11 +104,11 @@ def run_single(workload, steps, warmup, batch, use_graph=True, cpu_baseline=True
     starts = np.arange(total_steps) * batch
     eng.set_epoch(ui, ai, t, starts, np.full(total_steps, batch), alphas_for(total_steps))
     if warmup:
-        eng.run(warmup, use_graph=use_graph)
+        eng.run(warmup, use_graph=use_graph, first_step=0)
     eng.synchronize()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    eng.run(steps, use_graph=use_graph)
+    eng.run(steps, use_graph=use_graph, first_step=warmup)
     eng.synchronize()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
