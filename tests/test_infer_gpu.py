@@ -180,6 +180,34 @@ def test_predict_grid_mfma_within_1e5_of_oracle_and_fp32_path():
     np.testing.assert_allclose(G[:40], Go, atol=1e-5)      # BASELINE bar
 
 
+@pytest.mark.parametrize("shape", [(303, 1776), (700, 17984), (1000, 64), (257, 128), (513, 4160), (40, 18000)])
+def test_predict_grid_mfma_row_quad_kernel_on_odd_shapes(shape, monkeypatch):
+    """n_anime % 4 == 0 takes k_predict_mfma2 (LDS-DMA tiles, 4 rows x 256 B per store; the test above has an n_anime
+    that is not: the dword-store kernel).  User counts that end inside a workgroup / a wave, tile counts that do not
+    divide into the anime parts, one to seven parts — within 3e-6 of the fp32 kernel, bit-identical whatever the part
+    count, and no byte written behind the grid."""
+    from anime_recommendations_amd import ops
+    n_users, n_a = shape
+    rng = np.random.default_rng(n_users + n_a)
+    U = torch.from_numpy(rng.normal(0, 0.05, (n_users + 5, 128)).astype(np.float32)).cuda()
+    A = torch.from_numpy(rng.normal(0, 0.05, (n_a, 128)).astype(np.float32)).cuda()
+    head = dict(w=1.3, b=0.1, gamma=0.9, beta=-0.2, mov_mean=0.05, mov_var=0.4)
+    users = rng.integers(0, n_users + 5, n_users).astype(np.int32)
+    Gf = ops.predict_grid(U, A, head, users).cpu().numpy()
+    first = None
+    for parts in (None, "1", "3", "7"):
+        if parts is None:
+            monkeypatch.delenv("ANIREC_PREDICT_PARTS", raising=False)
+        else:
+            monkeypatch.setenv("ANIREC_PREDICT_PARTS", parts)
+        out = torch.full((n_users + 3, n_a), -7.0, device="cuda")        # rows behind the grid must stay untouched
+        ops.predict_grid_mfma(U, A, head, users, out=out[:n_users])
+        assert bool((out[n_users:] == -7.0).all())
+        np.testing.assert_allclose(out[:n_users].cpu().numpy(), Gf, atol=3e-6)
+        first = out[:n_users].clone() if first is None else first
+        assert torch.equal(out[:n_users], first), (shape, parts)
+
+
 def _watched_bits(rng, nq, n_a, frac):
     w = rng.random((nq, n_a)) < frac
     bits = np.zeros((nq, (n_a + 31) // 32), np.uint32)
