@@ -27,6 +27,33 @@ def test_encode_ids_is_first_appearance_order_and_matches_oracle():
     assert (s.map(m).to_numpy() == idx).all()
 
 
+def test_frame_to_columns_nulls_and_the_id_bounds_it_hands_on():
+    """ingest.frame_to_columns (host side of the GPU ingest): NaN in an integer column becomes NULL_I32, the rating
+    stays float64 with NaN, and the id bounds (max + 1 of the non-missing ids: the sizes of the direct-index tables)
+    are taken while the frame is still on the host, so that preprocess_columns / encode_columns need no pass over the
+    device columns for them."""
+    import pandas as pd
+    import torch
+    from anime_recommendations_amd import ingest
+    df = pd.DataFrame({"user_id": [3.0, np.nan, 9.0, 0.0], "anime_id": [7, 2, 41, 41], "rating": [1.0, np.nan, 3.5, 0.0],
+                       "watching_status": [1.0, 2.0, np.nan, 6.0], "watched_episodes": [0, 1, 1, 12]})
+    cols = ingest.frame_to_columns(df, device="cpu")
+    assert isinstance(cols, ingest.Columns) and cols.bounds == {"user_id": 10, "anime_id": 42}
+    assert cols["user_id"].tolist() == [3, ingest.NULL_I32, 9, 0] and cols["user_id"].dtype == torch.int32
+    assert cols["watching_status"].tolist() == [1, 2, ingest.NULL_I32, 6]
+    assert cols["rating"].dtype == torch.float64 and bool(torch.isnan(cols["rating"][1])) and float(cols["rating"][2]) == 3.5
+    empty = ingest.frame_to_columns(df.iloc[:0], device="cpu")
+    assert empty.bounds == {"user_id": 1, "anime_id": 1} and all(v.numel() == 0 for v in empty.values())
+    only_null = ingest.frame_to_columns(df.iloc[[1]].assign(anime_id=np.nan), device="cpu")
+    assert only_null.bounds == {"user_id": 1, "anime_id": 1}
+    with pytest.raises(ValueError):
+        ingest.frame_to_columns(df.assign(user_id=[0.5, 1, 2, 3]), device="cpu")        # not an integer column
+    with pytest.raises(ValueError):
+        ingest.frame_to_columns(df.assign(anime_id=[2 ** 31, 1, 2, 3]), device="cpu")   # does not fit int32
+    # a plain dict of columns is still accepted everywhere a Columns is (no bounds: they are computed)
+    assert ingest.Columns({"a": 1}).bounds == {}
+
+
 def test_shuffle_order_equals_pandas_sample():
     df = pd.DataFrame({"a": np.arange(1000)})
     assert (df.sample(frac=1, random_state=42)["a"].to_numpy() == data.shuffle_order(1000, 42)).all()
