@@ -287,3 +287,63 @@ def test_encode_id_space_at_the_lds_table_limit():
         want_idx, want_uniq = orc.encode(pd.Series(ids))
         np.testing.assert_array_equal(idx.cpu().numpy(), want_idx)
         np.testing.assert_array_equal(uniq.cpu().numpy(), want_uniq)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_preprocess_random_layouts_against_pandas(seed):
+    """Differential fuzz of the ownership logic of k_ing_front: tables built from random pieces — user blocks of a few
+    rows up to well over a chunk + its reach (12 000 rows), stretches in random order, the same user in several
+    places, single rows of other users dropped into blocks, rows with missing values, duplicates near and far —
+    with random flags and thresholds.  Whatever the workgroups decide about who owns which user, pandas' answer must
+    come out, bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    n_anime = int(rng.integers(30, 3000))
+    parts, uid = [], 1
+    target = int(rng.integers(20_000, 70_000))
+    total = 0
+    while total < target:
+        kind = rng.random()
+        if kind < 0.7:                                   # one user's block
+            ln = int(min(12_000, max(1, rng.lognormal(5.5, 1.6))))
+            users = np.full(ln, uid)
+            uid += int(rng.integers(1, 4))
+        elif kind < 0.85:                                # a stretch in random order over a few (partly earlier) users
+            ln = int(rng.integers(50, 4000))
+            pool = rng.integers(max(1, uid - 6), uid + 4, int(rng.integers(2, 9)))
+            users = rng.choice(pool, ln)
+            uid += 4
+        else:                                            # an earlier user comes back
+            ln = int(rng.integers(1, 600))
+            users = np.full(ln, int(rng.integers(1, uid + 1)))
+        parts.append(users)
+        total += ln
+    users = np.concatenate(parts)
+    n = len(users)
+    df = pd.DataFrame({"user_id": users, "anime_id": rng.integers(1, n_anime, n), "rating": rng.integers(0, 11, n),
+                       "watching_status": rng.choice([1, 2, 3, 4, 6], n), "watched_episodes": rng.integers(0, 30, n)})
+    for _ in range(int(rng.integers(0, 40))):            # single rows copied elsewhere (user id and all)
+        df.iloc[int(rng.integers(0, n))] = df.iloc[int(rng.integers(0, n))].to_numpy()
+    src = rng.integers(0, n, n // 30)                    # duplicates a few rows further on
+    dst = np.minimum(src + rng.integers(1, 80, len(src)), n - 1)
+    df.iloc[dst] = df.iloc[src].to_numpy()
+    if rng.random() < 0.6:
+        df = df.astype("float64")
+        for col in df.columns:
+            df.loc[rng.integers(0, n, int(rng.integers(1, 30))), col] = np.nan
+    if rng.random() < 0.3:                               # non-integer ratings: the rating-key fast path must not bite
+        df["rating"] = df["rating"].astype("float64") * 0.37
+    flags = dict(drop_unwatched=bool(rng.random() < 0.4), drop_plan=bool(rng.random() < 0.5),
+                 drop_half_watched=bool(rng.random() < 0.3))
+    counts = df["user_id"].value_counts()
+    for num_reviews in (1, int(counts.median()) + 1, int(counts.quantile(0.9)) + 1):
+        try:
+            want = orc.preprocess(df, num_reviews, flags["drop_unwatched"], flags["drop_plan"], flags["drop_half_watched"])
+        except ZeroDivisionError:
+            with pytest.raises(ZeroDivisionError):
+                _gpu_preprocess(df, num_reviews=num_reviews, **flags)
+            continue
+        if len(want) == 0:
+            got = _gpu_preprocess(df, num_reviews=num_reviews, **flags)
+            assert len(got["user_id"]) == 0
+            continue
+        _check(df, num_reviews, **flags)
