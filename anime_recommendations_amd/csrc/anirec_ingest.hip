@@ -908,8 +908,8 @@ __global__ __launch_bounds__(kEncLdsThreads) void k_enc_first_lds(const int32_t 
       for (int j = 0; j < 4; ++j) {
         if (v[j] < 0 || v[j] >= bound)
           bad |= ik < hi && ik + j < n;
-        else
-          atomicMin(&tab[v[j]], (int32_t)(ik + j));
+        else if (tab[v[j]] > (int32_t)(ik + j))  // (the range ascends: past its first rows an id never wins again — a
+          atomicMin(&tab[v[j]], (int32_t)(ik + j));  //  plain LDS read instead of an atomic for nearly every row)
       }
     }
   }
