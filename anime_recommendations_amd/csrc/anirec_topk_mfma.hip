@@ -593,7 +593,7 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void k_cand(CandArgs a) {
           if (mk) {  // wave-uniform
             const uint32_t mh = (uint32_t)(mk >> sh16) & 0xFFFFu;  // the quarter-wave (= row) of this lane
             const uint32_t pos = (uint32_t)cntr[rb][i] + __popc(mh & lt16);
-            if (hit && pos < cap)
+            if (kDbg != 8 && hit && pos < cap)  // (kDbg 8, timing only: everything but the candidate store)
               *reinterpret_cast<uint2 *>(cand_bytes + (rowoff[rb][i] + pos * 8u)) =
                   make_uint2(__float_as_uint(cv[i] - nthr[rb][i]), (uint32_t)key);
             cntr[rb][i] += __popc(mh);
@@ -1195,6 +1195,8 @@ static int run_super_steps(CandArgs &ca, int n, int nq, bool masked, int mode, v
       ANIREC_LAUNCH_CAND(2, false);
     else if (mode == 4)
       ANIREC_LAUNCH_CAND(4, false);
+    else if (mode == 8)
+      ANIREC_LAUNCH_CAND(8, false);
     else
       ANIREC_LAUNCH_CAND(0, false);
 #undef ANIREC_LAUNCH_CAND
@@ -1772,7 +1774,7 @@ int anirec_cosine_topk_job(const float *What, int32_t n, const int32_t *queries,
   const char *sg = getenv("ANIREC_TOPK_STAGGER_PCT");
   const int stagger = sg ? atoi(sg) : 0;
   const char *dbg = getenv("ANIREC_TOPK_DEBUG");
-  const int mode = dbg && atoi(dbg) == 1 ? 1 : 0;  // 1: timing-only build of k_cand without the filter
+  const int mode = dbg && (atoi(dbg) == 1 || atoi(dbg) == 8) ? atoi(dbg) : 0;  // timing-only builds of k_cand: 1 without the filter, 8 without the candidate stores
   for (int i = 0; b < n_batches; ++b, ++i) {
     const int l = i % lanes;
     hipStream_t st = l == 0 ? s : pool->side[l - 1];
