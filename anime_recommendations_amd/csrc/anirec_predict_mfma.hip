@@ -324,11 +324,15 @@ __global__ __launch_bounds__(256, 2) void k_predict_mfma2(PredArgs a) {
   for (; t + 1 < ntiles; t += 2) {
     if (t + 1 < ntiles) dma_tile(tb + t + 1, 0);
     step(accB, accA, 1, tb + t - 1, true);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the tile landed; the 8 younger stores stay in flight
+    // the tile landed.  (Rounds 2-4 waited vmcnt(8) — "the 8 younger stores stay in flight" — which leans on one wave's
+    // loads and stores retiring in issue order; the counter is shared but that order is not documented for a mix of the
+    // two.  Draining the stores as well measured the same to half a per cent — 1.983 / 1.956 against 1.980 / 1.946 ms,
+    // interleaved on one box — so the wait no longer depends on it.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t + 2 < ntiles) dma_tile(tb + t + 2, 1);
     step(accA, accB, 0, tb + t, true);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   if (t < ntiles) {  // one tile left (in buffer 1), results of tile t-1 in accA
