@@ -1774,7 +1774,9 @@ int anirec_cosine_topk_job(const float *What, int32_t n, const int32_t *queries,
   const char *sg = getenv("ANIREC_TOPK_STAGGER_PCT");
   const int stagger = sg ? atoi(sg) : 0;
   const char *dbg = getenv("ANIREC_TOPK_DEBUG");
-  const int mode = dbg && (atoi(dbg) == 1 || atoi(dbg) == 8) ? atoi(dbg) : 0;  // timing-only builds of k_cand: 1 without the filter, 8 without the candidate stores
+  // diagnostic builds of k_cand: 1 without the filter, 8 without the candidate stores (timing only), 4 with in-kernel
+  // stamps of the last super-step of every batch (printed to stderr; results valid)
+  const int mode = dbg && (atoi(dbg) == 1 || atoi(dbg) == 8 || atoi(dbg) == 4) ? atoi(dbg) : 0;
   for (int i = 0; b < n_batches; ++b, ++i) {
     const int l = i % lanes;
     hipStream_t st = l == 0 ? s : pool->side[l - 1];
