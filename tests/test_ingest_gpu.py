@@ -347,3 +347,34 @@ def test_preprocess_random_layouts_against_pandas(seed):
             assert len(got["user_id"]) == 0
             continue
         _check(df, num_reviews, **flags)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_encode_random_columns_against_series_unique(seed):
+    """Differential fuzz of the id encoders: columns with long runs (a table grouped by the column: unread atomics at
+    the run ends), without runs (read before update), mixtures, id spaces on both sides of the 32 768-id LDS-table
+    limit, lengths that are multiples of nothing, caller-supplied loose bounds — always Series.unique() order."""
+    from anime_recommendations_amd import ingest
+    rng = np.random.default_rng(500 + seed)
+    for _ in range(4):
+        n = int(rng.integers(1, 400_000))
+        hi = int(rng.choice([3, 200, 18_000, 32_768, 32_769, 90_000, 400_000]))
+        kind = rng.random()
+        if kind < 0.35:
+            ids = rng.integers(0, hi, n)
+        elif kind < 0.7:                                  # runs: sorted, or blocks in random order of ids
+            ids = np.sort(rng.integers(0, hi, n)) if rng.random() < 0.5 else np.repeat(
+                rng.permutation(hi)[:max(1, n // 50)], 50)[:n]
+            if len(ids) < n:
+                ids = np.concatenate([ids, rng.integers(0, hi, n - len(ids))])
+        else:                                             # runs with strangers sprinkled in
+            ids = np.sort(rng.integers(0, hi, n))
+            at = rng.integers(0, n, max(1, n // 100))
+            ids[at] = rng.integers(0, hi, len(at))
+        ids = ids.astype(np.int32)
+        want_idx, want_uniq = orc.encode(pd.Series(ids))
+        t = torch.as_tensor(ids, device="cuda")
+        for bound in (None, int(ids.max()) + 1 + int(rng.integers(0, 5000))):
+            idx, uniq = ingest.encode_ids(t, bound=bound)
+            np.testing.assert_array_equal(idx.cpu().numpy(), want_idx)
+            np.testing.assert_array_equal(uniq.cpu().numpy(), want_uniq)
