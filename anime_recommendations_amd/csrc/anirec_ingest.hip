@@ -1000,6 +1000,32 @@ __global__ __launch_bounds__(256) void k_ing_id_max(const int32_t *user, const i
   }
 }
 
+// every table a preprocess / an encode call starts from, in ONE launch each (seven / three fills otherwise: the
+// launches between them are most of what a fill of a megabyte costs)
+__global__ __launch_bounds__(256) void k_ing_init(int32_t *err, int32_t *cnt_u, int32_t *ufirst, int32_t *ulast, int ub,
+                                                  int32_t *tile_cnt, int n_tiles, unsigned long long *mm, int32_t *nl_count) {
+  const int stride = gridDim.x * 256;
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < ub; v += stride) {
+    cnt_u[v] = 0;
+    ufirst[v] = 0x7FFFFFFF;
+    ulast[v] = -1;
+  }
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < n_tiles; t += stride) tile_cnt[t] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *err = 0;
+    mm[0] = ~0ULL;  // min of the surviving ratings (order-preserving keys)
+    mm[1] = 0ULL;   // max
+    nl_count[0] = 0;
+    nl_count[1] = 0;
+  }
+}
+__global__ __launch_bounds__(256) void k_enc_init(int32_t *err, uint32_t *bits, size_t n_words, int32_t *first, int bound) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t x = (size_t)blockIdx.x * 256 + threadIdx.x; x < n_words; x += stride) bits[x] = 0u;
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < (size_t)bound; v += stride) first[v] = 0x7FFFFFFF;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *err = 0;
+}
+
 static inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 static inline size_t pad_tile(int64_t n) { return ((size_t)n + kChunk - 1) / kChunk * kChunk; }  // whole chunks
 static inline uint32_t table_slots(int64_t n) {
@@ -1099,13 +1125,12 @@ int anirec_ingest_preprocess(const int32_t *user_id, const int32_t *anime_id, co
   const IngestCols c{user_id, anime_id, rating, watching_status, watched_episodes};
   const int g = grid_for(n);
   const int gl = 4096;  // the list kernels read the list length on the device
-  ANIREC_HIP_CHECK(hipMemsetAsync(err_flag, 0, 4, s));
-  ANIREC_HIP_CHECK(hipMemsetAsync(w.cnt_u, 0, ub * 4, s));
-  ANIREC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)w.ufirst, 0x7FFFFFFF, ub, s));
-  ANIREC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)w.ulast, -1, ub, s));
-  ANIREC_HIP_CHECK(hipMemsetAsync(w.mm, 0xFF, 8, s));
-  ANIREC_HIP_CHECK(hipMemsetAsync(w.mm + 1, 0, 16, s));  // max, list length
-  ANIREC_HIP_CHECK(hipMemsetAsync(w.bsum, 0, (size_t)n_tiles * 4, s));
+  {
+    const size_t most = ub > (size_t)n_tiles ? ub : (size_t)n_tiles;
+    const unsigned gi = (unsigned)((most + 255) / 256 > 2048 ? 2048 : (most + 255) / 256);
+    hipLaunchKernelGGL(k_ing_init, dim3(gi), dim3(256), 0, s, err_flag, w.cnt_u, w.ufirst, w.ulast, (int)ub, w.bsum, n_tiles,
+                       w.mm, w.nl_count);
+  }
   hipLaunchKernelGGL(k_ing_span, dim3(quad_grid(n, kSpanIters)), dim3(256), 0, s, user_id, n, opts->user_id_bound,
                      w.ufirst, w.ulast);
   const FrontArgs fa{c,        n,        opts->drop_unwatched, opts->drop_plan, opts->user_id_bound, opts->anime_id_bound,
@@ -1183,9 +1208,11 @@ int anirec_ingest_encode(const int32_t *id, int64_t n, int32_t id_bound, int32_t
   int32_t *bsum = (int32_t *)p;
   const int gb = (id_bound + 255) / 256;
   const int nb = (int)(nw / kBitTile);
-  ANIREC_HIP_CHECK(hipMemsetAsync(err_flag, 0, 4, s));
-  ANIREC_HIP_CHECK(hipMemsetAsync(bits, 0, nw * 4, s));
-  ANIREC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)first, 0x7FFFFFFF, (size_t)id_bound, s));
+  {
+    const size_t most = nw > (size_t)id_bound ? nw : (size_t)id_bound;
+    const unsigned gi = (unsigned)((most + 255) / 256 > 2048 ? 2048 : (most + 255) / 256);
+    hipLaunchKernelGGL(k_enc_init, dim3(gi), dim3(256), 0, s, err_flag, bits, nw, first, id_bound);
+  }
   const bool lds = id_bound <= kEncLdsIds;  // the id tables fit a CU's LDS
   if (lds) {
     hipLaunchKernelGGL(k_enc_first_lds, dim3(enc_lds_grid(n)), dim3(kEncLdsThreads), 0, s, id, n, id_bound, first, err_flag);
