@@ -54,6 +54,66 @@ def test_frame_to_columns_nulls_and_the_id_bounds_it_hands_on():
     assert ingest.Columns({"a": 1}).bounds == {}
 
 
+def test_ingest_ownership_rule_gives_every_row_one_writer():
+    """The rule k_ing_front (csrc/anirec_ingest.hip) decides ownership by, restated in NumPy: the table is cut into chunks
+    of 8 192 rows; reach(end) = rows the last user of the chunk ending at `end` continues past it (0 if that user
+    started before the chunk or continues for 4 096 rows or more); a user is OWNED by the chunk its first row lies in
+    if its last row lies before that chunk's end + reach.  A workgroup writes the flags of its chunk's rows except
+    those whose user the left neighbour owns, plus the rows behind its chunk (up to its reach) whose user it owns.
+    For any row order every row must have exactly one writer, and every row of an owned user the same one."""
+    chunk, ext = 8192, 4096
+    rng = np.random.default_rng(3)
+
+    def check(users):
+        n = len(users)
+        ids = np.unique(users[users >= 0])
+        first = {u: int(np.flatnonzero(users == u)[0]) for u in ids}
+        last = {u: int(np.flatnonzero(users == u)[-1]) for u in ids}
+
+        def reach(end):
+            if end <= 0 or end >= n or users[end - 1] < 0:
+                return 0
+            u = users[end - 1]
+            return last[u] - end + 1 if first[u] >= end - chunk and end <= last[u] < end + ext else 0
+
+        def owns(j, u):
+            base = j * chunk
+            return base <= first[u] < base + chunk and last[u] < base + chunk + reach(base + chunk)
+
+        writers = np.zeros(n, dtype=int)
+        owner_of_row = np.full(n, -1)
+        for j in range((n + chunk - 1) // chunk):
+            base = j * chunk
+            for r in range(base, min(n, base + chunk)):
+                u = users[r]
+                if u >= 0 and j > 0 and owns(j - 1, u):
+                    continue                       # the left neighbour reads on to this row
+                writers[r] += 1
+                owner_of_row[r] = j if (u >= 0 and owns(j, u)) else -2     # -2: its user is nobody's (the list)
+            for r in range(base + chunk, min(n, base + chunk + reach(base + chunk))):
+                if users[r] >= 0 and owns(j, users[r]):
+                    writers[r] += 1
+                    owner_of_row[r] = j
+        assert (writers == 1).all(), np.flatnonzero(writers != 1)[:10]
+        for u in ids:
+            rows = np.flatnonzero(users == u)
+            assert len(set(owner_of_row[rows])) == 1, u       # owned whole by one workgroup, or nobody's everywhere
+
+    def blocks(lengths):
+        return np.repeat(np.arange(len(lengths)), lengths)
+
+    check(blocks([5000, 2492, 700 + 4095, 300, 8192 * 2 + 11, 250, 6000]))        # reach 4 095: owned
+    check(blocks([5000, 2492, 700 + 4096, 300, 9000]))                              # reach 4 096: nobody's
+    check(blocks([8192, 8192, 1, 8191, 3]))                                          # blocks ending on the boundaries
+    u = blocks([3000, 5000, 400, 7900, 300, 8100, 2000])
+    u[[8190, 8192, 8600, 16384, 12000, 5]] = [0, 0, 6, 1, 3, 4]                      # single rows of other users
+    u[[100, 9000]] = -1                                                              # rows without a valid user id
+    check(u)
+    check(rng.integers(0, 40, 30000))                                                # random order: nobody owns anybody
+    mix = np.concatenate([blocks([4000, 6000, 300]), rng.integers(0, 5, 2000), blocks([9000, 50]) + 10])
+    check(mix)
+
+
 def test_shuffle_order_equals_pandas_sample():
     df = pd.DataFrame({"a": np.arange(1000)})
     assert (df.sample(frac=1, random_state=42)["a"].to_numpy() == data.shuffle_order(1000, 42)).all()
